@@ -1,0 +1,435 @@
+"""Host-side mirror of the reference's ``calib::estimation_optim`` free functions.
+
+Same names, argument meaning, defaults and error behaviour as
+``include/calib/estimation/optim/{optimize,intrinsics,extrinsics,bundle,handeye}.h`` of the
+reference, expressed on numpy containers:
+
+* ``PlanarView``         -> ``ndarray (N, 4)`` rows ``[X, Y, u, v]`` (PlanarObservation, linear/planarpose.h:22-26)
+* ``MulticamPlanarView`` -> ``list[PlanarView]`` indexed by camera (linear/extrinsics.h:20)
+* ``Eigen::Isometry3d``  -> ``ndarray (4, 4)``
+* camera                 -> ``ndarray (10,)`` pinhole+Brown-Conrady or ``(12,)`` Scheimpflug, in
+  ``CameraTraits::to_array`` order (pinhole.h:135-146, scheimpflug.h:249-260)
+
+Everything is flattened to SoA and handed to the C ABI (``include/calibba.h``); all arithmetic on
+the path runs in libcalibba's HIP kernels.  ``std::invalid_argument`` maps to ``ValueError``
+(``CbaInvalidArgument``), ``std::runtime_error`` to ``CbaError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import CbaOptions, CbaReprojProblem, CbaSummary, dptr, i32ptr, i64ptr
+
+
+# ---- option / result types (optimize.h:17-40 etc.) ----------------------------------------------
+@dataclass
+class OptimOptions:
+    optimizer: int = 0  # OptimizerType::DEFAULT
+    huber_delta: float = 1.0
+    epsilon: float = 1e-9
+    max_iterations: int = 1000
+    compute_covariance: bool = True
+    verbose: bool = False
+
+
+@dataclass
+class OptimResult:
+    success: bool = False
+    covariance: Optional[np.ndarray] = None  # empty in the reference when rank deficient / disabled
+    report: str = "Empty"
+    final_cost: float = 0.0
+    iterations: int = 0
+    initial_cost: float = 0.0
+    solve_seconds: float = 0.0
+
+
+@dataclass
+class IntrinsicsOptimOptions:  # intrinsics.h:13-20
+    core: OptimOptions = field(default_factory=OptimOptions)
+    num_radial: int = 2  # read by nobody in optimize_intrinsics (intrinsics.cpp:70-87), kept for parity
+    optimize_skew: bool = False
+
+
+@dataclass
+class ExtrinsicOptions:  # extrinsics.h:22-27
+    core: OptimOptions = field(default_factory=OptimOptions)
+    optimize_intrinsics: bool = True
+    optimize_skew: bool = False
+    optimize_extrinsics: bool = True
+
+
+@dataclass
+class BundleOptions:  # bundle.h:30-36
+    core: OptimOptions = field(default_factory=OptimOptions)
+    optimize_intrinsics: bool = False
+    optimize_skew: bool = False
+    optimize_target_pose: bool = True
+    optimize_hand_eye: bool = True
+
+
+@dataclass
+class BundleObservation:  # bundle.h:22-26
+    view: np.ndarray
+    b_se3_g: np.ndarray
+    camera_index: int = 0
+
+
+@dataclass
+class IntrinsicsOptimizationResult:  # intrinsics.h:22-28
+    core: OptimResult
+    camera: np.ndarray
+    c_se3_t: List[np.ndarray]
+    view_errors: List[float] = field(default_factory=list)  # never filled by optimize_intrinsics
+
+
+@dataclass
+class ExtrinsicOptimizationResult:  # extrinsics.h:14-20
+    core: OptimResult
+    cameras: List[np.ndarray]
+    c_se3_r: List[np.ndarray]
+    r_se3_t: List[np.ndarray]
+
+
+@dataclass
+class BundleResult:  # bundle.h:39-45
+    core: OptimResult
+    cameras: List[np.ndarray]
+    g_se3_c: List[np.ndarray]
+    b_se3_t: np.ndarray
+
+
+@dataclass
+class HandeyeResult:  # handeye.h:16-19
+    core: OptimResult
+    g_se3_c: np.ndarray
+
+
+# ---- pose helpers (observationutils.h:43-62): host logic, see geometry.py -----------------------
+from .geometry import pose_from_matrix, pose_to_matrix  # noqa: E402
+
+
+def camera_model_of(cam: np.ndarray) -> int:
+    n = int(np.asarray(cam).shape[-1])
+    if n == 10:
+        return capi.CAMERA_PINHOLE_BC
+    if n == 12:
+        return capi.CAMERA_SCHEIMPFLUG
+    raise ValueError(f"camera parameter vector must have 10 or 12 entries, got {n}")
+
+
+def to_cba_options(core: OptimOptions, optimize_intrinsics=True, optimize_skew=False, optimize_extrinsics=True,
+                   optimize_target_pose=True) -> CbaOptions:
+    o = CbaOptions()
+    o.optimizer = int(core.optimizer)
+    o.max_iterations = int(core.max_iterations)
+    o.huber_delta = float(core.huber_delta)
+    o.epsilon = float(core.epsilon)
+    o.compute_covariance = int(bool(core.compute_covariance))
+    o.verbose = int(bool(core.verbose))
+    o.optimize_intrinsics = int(bool(optimize_intrinsics))
+    o.optimize_skew = int(bool(optimize_skew))
+    o.optimize_extrinsics = int(bool(optimize_extrinsics))
+    o.optimize_target_pose = int(bool(optimize_target_pose))
+    return o
+
+
+def result_core(s: CbaSummary, cov: Optional[np.ndarray]) -> OptimResult:
+    return OptimResult(
+        success=bool(s.success),
+        covariance=cov,
+        report=s.report.decode("utf-8", "replace"),
+        final_cost=float(s.final_cost),
+        iterations=int(s.iterations),
+        initial_cost=float(s.initial_cost),
+        solve_seconds=float(s.solve_seconds),
+    )
+
+
+# ---- flattening: AoS host containers -> SoA + CSR ------------------------
+class FlatProblem:
+    """Owns the numpy buffers a ``cba_reproj_problem`` points into."""
+
+    def __init__(self, chain: int, model: int, views: Sequence[np.ndarray], blk_cam, blk_view, intr, cam_pose,
+                 view_pose, target_pose, blk_b_T_g=None, first_view_global: int = 0):
+        self.chain, self.model = chain, model
+        counts = [int(np.asarray(v).reshape(-1, 4).shape[0]) if np.asarray(v).size else 0 for v in views]
+        self.blk_offset = np.zeros(len(views) + 1, dtype=np.int64)
+        np.cumsum(counts, out=self.blk_offset[1:])
+        if len(views) and self.blk_offset[-1] > 0:
+            allv = np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views], axis=0)
+        else:
+            allv = np.zeros((0, 4))
+        self.X = np.ascontiguousarray(allv[:, 0])
+        self.Y = np.ascontiguousarray(allv[:, 1])
+        self.u = np.ascontiguousarray(allv[:, 2])
+        self.v = np.ascontiguousarray(allv[:, 3])
+        self.blk_cam = np.ascontiguousarray(blk_cam, dtype=np.int32)
+        self.blk_view = None if blk_view is None else np.ascontiguousarray(blk_view, dtype=np.int32)
+        self.blk_b_T_g = None if blk_b_T_g is None else np.ascontiguousarray(blk_b_T_g, dtype=np.float64)
+        self.intr = np.ascontiguousarray(intr, dtype=np.float64).copy()
+        self.cam_pose = None if cam_pose is None else np.ascontiguousarray(cam_pose, dtype=np.float64).copy()
+        self.view_pose = None if view_pose is None else np.ascontiguousarray(view_pose, dtype=np.float64).copy()
+        self.target_pose = None if target_pose is None else np.ascontiguousarray(target_pose, dtype=np.float64).copy()
+        self.n_blocks = len(views)
+        self.n_cams = int(self.intr.reshape(-1, capi_intr_size(model)).shape[0]) if self.intr.size else 0
+        self.n_views = 0 if self.view_pose is None else int(self.view_pose.reshape(-1, 7).shape[0])
+        self.first_view_global = int(first_view_global)
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.blk_offset[-1])
+
+    def struct(self) -> CbaReprojProblem:
+        d = CbaReprojProblem()
+        d.chain, d.camera_model = self.chain, self.model
+        d.n_blocks, d.n_cams, d.n_views = self.n_blocks, self.n_cams, self.n_views
+        d.first_view_global = self.first_view_global
+        d.blk_offset = i64ptr(self.blk_offset)
+        d.blk_cam = i32ptr(self.blk_cam)
+        d.blk_view = i32ptr(self.blk_view)
+        d.blk_b_T_g = dptr(self.blk_b_T_g)
+        d.X, d.Y, d.u, d.v = dptr(self.X), dptr(self.Y), dptr(self.u), dptr(self.v)
+        d.intr = dptr(self.intr)
+        d.cam_pose = dptr(self.cam_pose)
+        d.view_pose = dptr(self.view_pose)
+        d.target_pose = dptr(self.target_pose)
+        return d
+
+
+def capi_intr_size(model: int) -> int:
+    return 12 if model == capi.CAMERA_SCHEIMPFLUG else 10
+
+
+def matrix_to_rt12(m: np.ndarray) -> np.ndarray:
+    m = np.asarray(m, dtype=np.float64).reshape(4, 4)
+    return np.concatenate([m[:3, :3].reshape(-1), m[:3, 3]])
+
+
+def flatten_intrinsics(views, init_camera, init_c_se3_t) -> FlatProblem:
+    model = camera_model_of(init_camera)
+    poses = np.stack([pose_from_matrix(m) for m in init_c_se3_t]) if len(init_c_se3_t) else np.zeros((0, 7))
+    nb = len(views)
+    return FlatProblem(capi.CHAIN_INTRINSIC, model, views, np.zeros(nb, np.int32), np.arange(nb, dtype=np.int32),
+                       np.asarray(init_camera, dtype=np.float64).reshape(1, -1), None, poses, None)
+
+
+def flatten_extrinsics(views, init_cameras, init_c_se3_r, init_r_se3_t) -> FlatProblem:
+    model = camera_model_of(init_cameras[0])
+    blocks, bcam, bview = [], [], []
+    for vi, mv in enumerate(views):
+        for ci in range(len(init_cameras)):
+            pv = np.asarray(mv[ci]).reshape(-1, 4) if ci < len(mv) else np.zeros((0, 4))
+            if pv.shape[0] == 0:  # extrinsics.cpp:94-96: empty per-camera view skipped
+                continue
+            blocks.append(pv)
+            bcam.append(ci)
+            bview.append(vi)
+    cams = np.stack([pose_from_matrix(m) for m in init_c_se3_r])
+    tgts = np.stack([pose_from_matrix(m) for m in init_r_se3_t]) if len(init_r_se3_t) else np.zeros((0, 7))
+    return FlatProblem(capi.CHAIN_EXTRINSIC, model, blocks, bcam, bview, np.stack(init_cameras), cams, tgts, None)
+
+
+def flatten_bundle(observations: Sequence[BundleObservation], cameras, init_g_se3_c, init_b_se3_t) -> FlatProblem:
+    model = camera_model_of(cameras[0]) if len(cameras) else capi.CAMERA_PINHOLE_BC
+    blocks = [np.asarray(o.view, dtype=np.float64).reshape(-1, 4) for o in observations]
+    bcam = [int(o.camera_index) for o in observations]
+    btg = np.stack([matrix_to_rt12(o.b_se3_g) for o in observations]) if len(observations) else np.zeros((0, 12))
+    g = np.stack([pose_from_matrix(m) for m in init_g_se3_c]) if len(init_g_se3_c) else np.zeros((0, 7))
+    intr = np.stack(cameras) if len(cameras) else np.zeros((0, 10))
+    return FlatProblem(capi.CHAIN_BUNDLE, model, blocks, bcam, None, intr, g, None, pose_from_matrix(init_b_se3_t), btg)
+
+
+# ---- handle wrapper ------------------------------------------------------------------------------
+class ReprojHandle:
+    """RAII wrapper of ``cba_reproj``: observations + parameters resident in HBM."""
+
+    def __init__(self, flat: FlatProblem, device: int = 0, lib=None):
+        self.lib = lib or capi.load_library()
+        self.flat = flat
+        self._desc = flat.struct()
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.cba_reproj_create(C.byref(self._desc), int(device), C.byref(h)))
+        self.h = h
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cba_reproj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.lib.cba_reproj_num_observations(self.h))
+
+    @property
+    def local_columns(self) -> int:
+        return int(self.lib.cba_local_columns(self.flat.chain, self.flat.model))
+
+    def set_params(self, intr=None, cam_pose=None, view_pose=None, target_pose=None):
+        f = self.flat
+        for name, val in (("intr", intr), ("cam_pose", cam_pose), ("view_pose", view_pose), ("target_pose", target_pose)):
+            if val is not None:
+                getattr(f, name)[...] = np.asarray(val, dtype=np.float64).reshape(getattr(f, name).shape)
+        capi.check(self.lib, self.lib.cba_reproj_set_params(self.h, dptr(f.intr), dptr(f.cam_pose), dptr(f.view_pose),
+                                                            dptr(f.target_pose)))
+
+    def get_params(self):
+        f = self.flat
+        capi.check(self.lib, self.lib.cba_reproj_get_params(self.h, dptr(f.intr), dptr(f.cam_pose), dptr(f.view_pose),
+                                                            dptr(f.target_pose)))
+        return f.intr, f.cam_pose, f.view_pose, f.target_pose
+
+    def eval(self):
+        capi.check(self.lib, self.lib.cba_reproj_eval(self.h))
+
+    def eval_fetch(self):
+        n, p = self.n_obs, self.local_columns
+        r = np.zeros(2 * n)
+        J = np.zeros((2 * n, p))
+        capi.check(self.lib, self.lib.cba_reproj_eval_fetch(self.h, dptr(r), dptr(J)))
+        return r, J
+
+    def eval_timed(self, warmup: int, iters: int) -> float:
+        ms = C.c_double(0.0)
+        capi.check(self.lib, self.lib.cba_reproj_eval_timed(self.h, int(warmup), int(iters), C.byref(ms)))
+        return float(ms.value)
+
+    def cost(self, huber_delta: float = 1.0) -> float:
+        c = C.c_double(0.0)
+        capi.check(self.lib, self.lib.cba_reproj_cost(self.h, float(huber_delta), C.byref(c)))
+        return float(c.value)
+
+    def block_normal_eq(self) -> np.ndarray:
+        w = int(self.lib.cba_reproj_block_normal_eq_size(self.h))
+        out = np.zeros((self.flat.n_blocks, w))
+        capi.check(self.lib, self.lib.cba_reproj_block_normal_eq(self.h, dptr(out)))
+        return out
+
+    def solve(self, opts: CbaOptions) -> CbaSummary:
+        s = CbaSummary()
+        capi.check(self.lib, self.lib.cba_reproj_solve(self.h, C.byref(opts), C.byref(s)))
+        self.get_params()
+        return s
+
+    def covariance(self, opts: CbaOptions) -> Optional[np.ndarray]:
+        dim = int(self.lib.cba_reproj_covariance_dim(self.h))
+        cov = np.zeros((dim, dim))
+        st = self.lib.cba_reproj_covariance(self.h, C.byref(opts), dptr(cov))
+        if st == capi.CBA_ERR_RUNTIME:  # rank deficient: the reference leaves the matrix empty
+            return None
+        capi.check(self.lib, st)
+        return cov
+
+    def set_allreduce(self, fn):
+        """fn(np.ndarray) sums the array in place across ranks (host buffers)."""
+
+        def _cb(buf, count, _user):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(int(count),))
+                fn(arr)
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        self._cb = capi.ALLREDUCE_FN(_cb)
+        capi.check(self.lib, self.lib.cba_reproj_set_allreduce(self.h, self._cb, None))
+
+    def init_rccl(self, unique_id: bytes, n_ranks: int, rank: int):
+        buf = (C.c_uint8 * capi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        capi.check(self.lib, self.lib.cba_reproj_init_rccl(self.h, buf, int(n_ranks), int(rank)))
+
+
+def rccl_unique_id(lib=None) -> bytes:
+    lib = lib or capi.load_library()
+    buf = (C.c_uint8 * capi.RCCL_UNIQUE_ID_BYTES)()
+    capi.check(lib, lib.cba_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def _solve_flat(flat: FlatProblem, copts: CbaOptions, device: int = 0):
+    with ReprojHandle(flat, device) as h:
+        s = h.solve(copts)
+        cov = h.covariance(copts) if copts.compute_covariance else None
+    return s, cov
+
+
+# ---- the reference's free functions ---------------------------------------------------------------
+def optimize_intrinsics(views, init_camera, init_c_se3_t, opts: Optional[IntrinsicsOptimOptions] = None,
+                        device: int = 0) -> IntrinsicsOptimizationResult:
+    """optimize_intrinsics<CameraT> (intrinsics.h:35-39, intrinsics.cpp:98-120)."""
+    opts = opts or IntrinsicsOptimOptions()
+    if len(views) < 4:  # intrinsics.cpp:92-96
+        raise capi.CbaInvalidArgument(capi.CBA_ERR_INVALID_ARGUMENT,
+                                      "Insufficient views for calibration (at least 4 required).")
+    flat = flatten_intrinsics(views, init_camera, init_c_se3_t)
+    s, cov = _solve_flat(flat, to_cba_options(opts.core, True, opts.optimize_skew), device)
+    return IntrinsicsOptimizationResult(result_core(s, cov), flat.intr.reshape(-1).copy(),
+                                        [pose_to_matrix(p) for p in flat.view_pose.reshape(-1, 7)])
+
+
+def optimize_extrinsics(views, init_cameras, init_c_se3_r, init_r_se3_t, opts: Optional[ExtrinsicOptions] = None,
+                        device: int = 0) -> ExtrinsicOptimizationResult:
+    """optimize_extrinsics<CameraT> (extrinsics.h:29-34, extrinsics.cpp:174-196)."""
+    opts = opts or ExtrinsicOptions()
+    if len(init_c_se3_r) != len(init_cameras) or len(init_r_se3_t) != len(views):  # extrinsics.cpp:162-172
+        raise capi.CbaInvalidArgument(capi.CBA_ERR_INVALID_ARGUMENT,
+                                      "Incompatible pose vector sizes for joint optimization")
+    flat = flatten_extrinsics(views, init_cameras, init_c_se3_r, init_r_se3_t)
+    s, cov = _solve_flat(flat, to_cba_options(opts.core, opts.optimize_intrinsics, opts.optimize_skew,
+                                              opts.optimize_extrinsics), device)
+    P = capi_intr_size(flat.model)
+    return ExtrinsicOptimizationResult(result_core(s, cov), [c.copy() for c in flat.intr.reshape(-1, P)],
+                                       [pose_to_matrix(p) for p in flat.cam_pose.reshape(-1, 7)],
+                                       [pose_to_matrix(p) for p in flat.view_pose.reshape(-1, 7)])
+
+
+def optimize_bundle(observations, initial_cameras, init_g_se3_c, init_b_se3_t, opts: Optional[BundleOptions] = None,
+                    device: int = 0) -> BundleResult:
+    """optimize_bundle<CameraT> (bundle.h:58-63, bundle.cpp:147-170)."""
+    opts = opts or BundleOptions()
+    if len(initial_cameras) == 0:  # bundle.cpp:139-141
+        raise capi.CbaInvalidArgument(capi.CBA_ERR_INVALID_ARGUMENT, "No camera intrinsics provided")
+    if len(observations) == 0:  # bundle.cpp:142-144
+        raise capi.CbaInvalidArgument(capi.CBA_ERR_INVALID_ARGUMENT, "No observations provided")
+    flat = flatten_bundle(observations, initial_cameras, init_g_se3_c, init_b_se3_t)
+    s, cov = _solve_flat(flat, to_cba_options(opts.core, opts.optimize_intrinsics, opts.optimize_skew,
+                                              opts.optimize_hand_eye, opts.optimize_target_pose), device)
+    P = capi_intr_size(flat.model)
+    return BundleResult(result_core(s, cov), [c.copy() for c in flat.intr.reshape(-1, P)],
+                        [pose_to_matrix(p) for p in flat.cam_pose.reshape(-1, 7)], pose_to_matrix(flat.target_pose))
+
+
+def optimize_handeye(base_se3_gripper, camera_se3_target, init_gripper_se3_ref, options: Optional[OptimOptions] = None
+                     ) -> HandeyeResult:
+    """optimize_handeye (handeye.h:40-43, handeye.cpp:60-78)."""
+    options = options or OptimOptions()
+    lib = capi.load_library()
+    n = len(base_se3_gripper)
+    bg = np.stack([pose_from_matrix(m) for m in base_se3_gripper]) if n else np.zeros((0, 7))
+    ct = np.stack([pose_from_matrix(m) for m in camera_se3_target]) if len(camera_se3_target) else np.zeros((0, 7))
+    if len(camera_se3_target) != n:
+        raise capi.CbaError(capi.CBA_ERR_RUNTIME, "Inconsistent hand-eye input sizes")
+    x = pose_from_matrix(init_gripper_se3_ref)
+    copts = to_cba_options(options)
+    s = CbaSummary()
+    cov = np.zeros((7, 7))
+    capi.check(lib, lib.cba_optimize_handeye(n, dptr(bg), dptr(ct), dptr(x), C.byref(copts), C.byref(s),
+                                             dptr(cov) if options.compute_covariance else dptr(None)))
+    return HandeyeResult(result_core(s, cov if options.compute_covariance else None), pose_to_matrix(x))

@@ -1,0 +1,236 @@
+/* calibba.h — C ABI of libcalibba.so, the MI355X (gfx950) bundle-adjustment engine that
+ * drops in behind VitalyVorobyev/calibration's `calib::estimation_optim` refinement API.
+ *
+ * Plain C: pointers, sizes, POD structs.  No C++/Eigen/torch types cross this boundary.
+ * All floating-point data is IEEE fp64; all matrices row-major unless stated.
+ * Every entry point returns a cba_status; cba_last_error() gives the message a C++ adapter
+ * re-throws (std::invalid_argument for CBA_ERR_INVALID_ARGUMENT, std::runtime_error for
+ * CBA_ERR_RUNTIME — the exception types of the reference, SURVEY.md §8b "Errors").
+ *
+ * Reference interface each group replaces (paths relative to the reference repo):
+ *   cba_options                 include/calib/estimation/optim/optimize.h:24-33 (OptimOptions)
+ *                               + intrinsics.h:13-20, extrinsics.h:22-27, bundle.h:30-36
+ *   cba_summary                 include/calib/estimation/optim/optimize.h:35-40 (OptimResult)
+ *   cba_optimize_intrinsics     include/calib/estimation/optim/intrinsics.h:35-39
+ *                               (src/estimation/optim/intrinsics.cpp:98-120)
+ *   cba_optimize_extrinsics     include/calib/estimation/optim/extrinsics.h:29-34
+ *                               (src/estimation/optim/extrinsics.cpp:174-196)
+ *   cba_optimize_bundle         include/calib/estimation/optim/bundle.h:58-63
+ *                               (src/estimation/optim/bundle.cpp:147-170)
+ *   cba_optimize_handeye        include/calib/estimation/optim/handeye.h:40-43
+ *                               (src/estimation/optim/handeye.cpp:60-78)
+ *   cba_reproj_* (handle API)   the ceres::Problem the reference builds and solves inside those
+ *                               functions (intrinsics.cpp:63-90, extrinsics.cpp:86-160,
+ *                               bundle.cpp:83-133, detail/ceresutils.h:27-43,69-126); exposed so
+ *                               observations can stay resident in HBM across solves and so the
+ *                               residual+Jacobian evaluation (ceres::CostFunction::Evaluate of
+ *                               residuals/intrinsicresidual.h:20-35, extrinsicsresidual.h:28-46,
+ *                               bundleresidual.h:36-56) can be called and timed on its own.
+ *
+ * Pose convention: a rigid transform is 7 doubles [qw, qx, qy, qz, tx, ty, tz] — exactly the
+ * parameter blocks the reference hands to Ceres (observationutils.h:43-48 populate_quat_tran;
+ * quaternion storage w,x,y,z, observationutils.h:20-24).  Results come back un-normalised, as in
+ * the reference's blocks; the caller applies restore_pose (observationutils.h:50-62).
+ * cba_pose_from_matrix / cba_pose_to_matrix restate those two helpers for hosts without Eigen.
+ *
+ * Camera parameter vectors follow CameraTraits (include/calib/models/pinhole.h:117-133,
+ * scheimpflug.h:234-261):
+ *   CBA_CAMERA_PINHOLE_BC   10: [fx, fy, cx, cy, skew, k1, k2, k3, p1, p2]
+ *   CBA_CAMERA_SCHEIMPFLUG  12: the above + [tau_x, tau_y]
+ *
+ * Threading: entry points are re-entrant; one handle must not be used from two threads at once.
+ */
+#ifndef CALIBBA_H
+#define CALIBBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBA_VERSION_STRING "0.1.0"
+
+typedef enum cba_status {
+    CBA_OK = 0,
+    CBA_ERR_INVALID_ARGUMENT = 1, /* reference throws std::invalid_argument */
+    CBA_ERR_RUNTIME = 2,          /* reference throws std::runtime_error */
+    CBA_ERR_NO_DEVICE = 3,        /* no usable gfx950 device: the engine has NO CPU fallback */
+    CBA_ERR_HIP = 4,              /* HIP / RCCL runtime error */
+    CBA_ERR_INTERNAL = 5
+} cba_status;
+
+typedef enum cba_chain {
+    CBA_CHAIN_INTRINSIC = 0, /* c_T_t = view pose                       (intrinsicresidual.h) */
+    CBA_CHAIN_EXTRINSIC = 1, /* c_T_t = c_T_r * r_T_t                   (extrinsicsresidual.h) */
+    CBA_CHAIN_BUNDLE = 2     /* c_T_t = g_T_c^-1 * b_T_g^-1 * b_T_t     (bundleresidual.h) */
+} cba_chain;
+
+typedef enum cba_camera_model { CBA_CAMERA_PINHOLE_BC = 0, CBA_CAMERA_SCHEIMPFLUG = 1 } cba_camera_model;
+
+typedef enum cba_termination {
+    CBA_TERM_CONVERGENCE = 0,    /* ceres::CONVERGENCE  -> success = true (ceresutils.h:42) */
+    CBA_TERM_NO_CONVERGENCE = 1, /* max_iterations hit  -> success = false */
+    CBA_TERM_FAILURE = 2
+} cba_termination;
+
+/* OptimOptions + the per-stage switches.  cba_options_default() gives the reference defaults. */
+typedef struct cba_options {
+    int32_t optimizer;            /* OptimizerType 0..3; accepted, ignored (one Schur solver) */
+    int32_t max_iterations;       /* 1000 */
+    double huber_delta;           /* 1.0; <= 0 disables the loss (intrinsics.cpp:70-71) */
+    double epsilon;               /* 1e-9: function, gradient and parameter tolerance */
+    int32_t compute_covariance;   /* 1 */
+    int32_t verbose;              /* 0 */
+    int32_t optimize_intrinsics;  /* ExtrinsicOptions (default 1) / BundleOptions (default 0);
+                                     ignored (always on) for the intrinsic chain */
+    int32_t optimize_skew;        /* 0 */
+    int32_t optimize_extrinsics;  /* ExtrinsicOptions::optimize_extrinsics (1) /
+                                     BundleOptions::optimize_hand_eye (1) */
+    int32_t optimize_target_pose; /* BundleOptions::optimize_target_pose (1) */
+} cba_options;
+
+/* OptimResult.  `covariance` is fetched separately (cba_reproj_covariance). */
+typedef struct cba_summary {
+    int32_t success;     /* termination == CONVERGENCE */
+    int32_t termination; /* cba_termination */
+    int32_t iterations;
+    int32_t successful_steps;
+    double initial_cost;
+    double final_cost; /* 1/2 sum_blocks rho(|r_block|^2), as ceres::Solver::Summary */
+    double solve_seconds;
+    char report[192]; /* brief report string (engine's own wording) */
+} cba_summary;
+
+/* One reprojection bundle problem.  A "residual block" is one planar view seen by one camera,
+ * exactly one ceres residual block of the reference (2*N residuals, one loss per block).
+ *
+ *   chain INTRINSIC: n_cams = 1; block b has private pose view_pose[blk_view[b]] (c_T_t)
+ *   chain EXTRINSIC: cam_pose[c] = c_T_r, view_pose[v] = r_T_t; block b = (view blk_view[b], cam blk_cam[b])
+ *   chain BUNDLE:    cam_pose[c] = g_T_c, target_pose = b_T_t, blk_b_T_g[b] = robot pose (data);
+ *                    n_views = 0
+ * Observations are SoA over all blocks, CSR-indexed by blk_offset.
+ */
+typedef struct cba_reproj_problem {
+    int32_t chain;        /* cba_chain */
+    int32_t camera_model; /* cba_camera_model */
+    int32_t n_blocks;
+    int32_t n_cams;
+    int32_t n_views;
+    int32_t reserved0;
+    int64_t first_view_global; /* index of local view 0 in the whole (multi-GPU) problem; the
+                                  gauge rule "first target pose constant" (extrinsics.cpp:123-126)
+                                  applies to global view 0 */
+    const int64_t* blk_offset; /* [n_blocks + 1] */
+    const int32_t* blk_cam;    /* [n_blocks] */
+    const int32_t* blk_view;   /* [n_blocks]; ignored for BUNDLE */
+    const double* blk_b_T_g;   /* BUNDLE: [n_blocks][12] = rotation row-major (9) + translation (3) */
+    const double* X;           /* [n_obs] target-plane x  (PlanarObservation::object_xy) */
+    const double* Y;           /* [n_obs] target-plane y */
+    const double* u;           /* [n_obs] pixel u         (PlanarObservation::image_uv) */
+    const double* v;           /* [n_obs] pixel v */
+    double* intr;              /* [n_cams][10|12]  in/out */
+    double* cam_pose;          /* [n_cams][7]      in/out (NULL for INTRINSIC) */
+    double* view_pose;         /* [n_views][7]     in/out (NULL for BUNDLE) */
+    double* target_pose;       /* [7]              in/out (BUNDLE only) */
+} cba_reproj_problem;
+
+typedef struct cba_reproj cba_reproj; /* opaque: owns device buffers + one HIP stream */
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* cba_version(void);
+const char* cba_last_error(void); /* thread-local, valid until the next call on this thread */
+int32_t cba_device_count(void);   /* number of visible HIP devices (0 if none) */
+void cba_options_default(cba_options* o);
+int32_t cba_intrinsics_size(int32_t camera_model); /* 10 or 12 */
+int32_t cba_local_columns(int32_t chain, int32_t camera_model); /* tangent columns per observation:
+                                     INTRINSIC 6+P, otherwise 12+P  [poseA d(3) t(3) | poseB d(3) t(3) | intr] */
+
+/* populate_quat_tran / restore_pose (observationutils.h:43-62) for 4x4 column-major matrices
+ * (the memory layout of Eigen::Isometry3d::data()). */
+void cba_pose_from_matrix(const double* m44_colmajor, double* pose7);
+void cba_pose_to_matrix(const double* pose7, double* m44_colmajor);
+
+/* ---- handle API --------------------------------------------------------------------------- */
+/* Validates like the reference (empty block -> INVALID_ARGUMENT "No observations provided",
+ * bad indices -> INVALID_ARGUMENT), copies observations into padded SoA device arrays and the
+ * parameters into device blocks.  Host buffers may be freed after this returns. */
+cba_status cba_reproj_create(const cba_reproj_problem* desc, int32_t device, cba_reproj** out);
+void cba_reproj_destroy(cba_reproj* h);
+cba_status cba_reproj_set_params(cba_reproj* h, const double* intr, const double* cam_pose,
+                                 const double* view_pose, const double* target_pose);
+cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, double* view_pose,
+                                 double* target_pose);
+int64_t cba_reproj_num_observations(const cba_reproj* h);
+
+/* Residual + tangent-space Jacobian of every observation at the current parameters ("Mode A").
+ * Output stays in HBM as SoA (r: [2][n_pad], J: [2*P][n_pad]); cba_reproj_eval_fetch copies it
+ * out in Ceres layout: r[2*n_obs] interleaved (u0,v0,u1,v1,..) per block, J row-major
+ * [2*n_obs][P] with the local column order of cba_local_columns().  Quaternion columns are in
+ * the tangent space of ceres::QuaternionManifold (ambient 2Nx4 Jacobian times PlusJacobian). */
+cba_status cba_reproj_eval(cba_reproj* h);
+cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J);
+/* Runs `iters` back-to-back evaluations on the handle's stream bracketed by HIP events;
+ * returns the average milliseconds per evaluation of the dominant kernel region. */
+cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_eval);
+
+/* Cost 1/2 sum rho(|r_b|^2) at the current parameters (residual-only pass). */
+cba_status cba_reproj_cost(cba_reproj* h, double huber_delta, double* cost);
+
+/* Per-block normal-equation blocks at the current parameters ("Mode B", unweighted):
+ * out[b] = [ upper triangle of J_b^T J_b row-major (P(P+1)/2) | J_b^T r_b (P) | |r_b|^2 (1) ]. */
+cba_status cba_reproj_block_normal_eq(cba_reproj* h, double* out);
+int64_t cba_reproj_block_normal_eq_size(const cba_reproj* h); /* doubles per block */
+
+/* Levenberg-Marquardt solve (what solve_problem + ceres::Solve do, ceresutils.h:27-43). */
+cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary* summary);
+
+/* Covariance in the reference's layout (ceresutils.h:69-126): dense symmetric, AMBIENT block
+ * sizes, block order = get_param_blocks() of the stage (intrinsics.cpp:34-50,
+ * extrinsics.cpp:50-67, bundle.cpp:48-68).  Returns CBA_ERR_RUNTIME if rank deficient (the
+ * reference then leaves the matrix empty). */
+int64_t cba_reproj_covariance_dim(const cba_reproj* h);
+cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double* cov /*[dim*dim]*/);
+
+/* ---- multi-GPU: views sharded across ranks, one sum-all-reduce per LM linear solve ---------- */
+/* Host-buffer callback (any transport: gloo, MPI, ...): in-place sum of buf[count] over ranks. */
+typedef int32_t (*cba_allreduce_fn)(double* buf, int64_t count, void* user);
+cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user);
+/* RCCL-native: device-buffer ncclAllReduce on the handle's stream (xGMI within a node). */
+#define CBA_RCCL_UNIQUE_ID_BYTES 128
+cba_status cba_rccl_unique_id(uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES]);
+cba_status cba_reproj_init_rccl(cba_reproj* h, const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES],
+                                int32_t n_ranks, int32_t rank);
+
+/* ---- one-shot entry points mirroring the reference's free functions ------------------------- */
+/* optimize_intrinsics: >= 4 views else INVALID_ARGUMENT (intrinsics.cpp:92-96).
+ * cov may be NULL; otherwise [(P + 7*n_views)^2], order [intr, quats..., trans...]. */
+cba_status cba_optimize_intrinsics(int32_t camera_model, int32_t n_views, const int64_t* view_offset,
+                                   const double* X, const double* Y, const double* u, const double* v,
+                                   double* intr, double* c_T_t /*[n_views][7]*/, const cba_options* opts,
+                                   cba_summary* summary, double* cov);
+/* optimize_extrinsics: views[v][c] = block; empty (view,cam) pairs are simply absent.
+ * cov order: [intr[c]..., cam quats..., cam trans..., view quats..., view trans...]. */
+cba_status cba_optimize_extrinsics(int32_t camera_model, int32_t n_cams, int32_t n_views, int32_t n_blocks,
+                                   const int64_t* blk_offset, const int32_t* blk_view, const int32_t* blk_cam,
+                                   const double* X, const double* Y, const double* u, const double* v,
+                                   double* intr, double* c_T_r, double* r_T_t, const cba_options* opts,
+                                   cba_summary* summary, double* cov);
+/* optimize_bundle: n_cams == 0 / n_blocks == 0 -> INVALID_ARGUMENT (bundle.cpp:139-144).
+ * cov order: [intr[c]..., g quats..., g trans..., b quat, b tran]. */
+cba_status cba_optimize_bundle(int32_t camera_model, int32_t n_cams, int32_t n_blocks,
+                               const int64_t* blk_offset, const int32_t* blk_cam, const double* blk_b_T_g,
+                               const double* X, const double* Y, const double* u, const double* v,
+                               double* intr, double* g_T_c, double* b_T_t, const cba_options* opts,
+                               cba_summary* summary, double* cov);
+/* optimize_handeye: AX = XB refinement over all motion pairs (handeye.cpp:60-78; pairs per
+ * src/estimation/linear/handeyedlt.cpp:51-81 with min angle 0.5 deg).  Poses are 7-vectors.
+ * RUNTIME error for < 2 poses / size mismatch / no valid pairs.  cov: [7*7] or NULL. */
+cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                double* g_T_c /*[7] in/out*/, const cba_options* opts, cba_summary* summary,
+                                double* cov);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALIBBA_H */
