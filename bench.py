@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — residual+Jacobian evals/sec of the reprojection hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): pinhole + Brown-Conrady intrinsics refinement, 1000 views x
+10000 points (100x100 planar grid), fp64, per GPU.  A "step" is one Mode A pass (k_eval): the
+2-vector residual and the 2x16 tangent-space Jacobian of every observation of this rank's views are
+produced and written to HBM, inputs already resident.  With N > 1 ranks each rank owns 1000 views of
+an N*1000-view problem (weak scaling, views sharded, no data-path collective inside the pass); the
+one real exchange of the path — the sum-all-reduce of the reduced normal equations per LM linear
+solve — is exercised by the LM solve reported under "lm" (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views", type=int, default=1000)
+    ap.add_argument("--grid", type=int, default=100, help="points per view = grid^2")
+    ap.add_argument("--no-lm", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from calibration_amd import capi, optim, synth
+
+    lib = capi.load_library()
+    if lib.cba_device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: libcalibba has no CPU fallback")
+
+    # ---- synthetic scene: this rank's shard of the (world * views)-view problem ----------------------
+    t_gen = time.time()
+    scene = synth.scene_intrinsics(args.views, rows=args.grid, cols=args.grid, spacing=0.2 / args.grid, seed=7 + rank,
+                                   noise_px=0.2, first_view_global=rank * args.views)
+    flat = scene.flat
+    init_intr, init_view = flat.intr.copy(), flat.view_pose.copy()
+    n_obs = flat.n_obs
+    t_gen = time.time() - t_gen
+    h = optim.ReprojHandle(flat, device=local_rank)
+    P = h.local_columns
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: W warmup + K steps of Mode A ---------------------------------------------------
+    h.eval_timed(0, max(1, args.warmup))
+    barrier()
+    t0 = time.perf_counter()
+    ms_kernel = h.eval_timed(0, args.steps)  # K back-to-back k_eval launches, HIP events on the engine's stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * n_obs * args.steps / elapsed
+
+    bytes_per_obs = 8 * (4 + 2 + 2 * P)  # 4 loads + 2 residual + 2P Jacobian stores, fp64
+    achieved = bytes_per_obs * n_obs / (ms_kernel * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_eval<INTRINSIC,PINHOLE_BC>",
+                "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
+
+    # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
+    lm = None
+    if not args.no_lm:
+        if world > 1:
+            uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.tensor(list(optim.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            h.init_rccl(bytes(uid.cpu().numpy().tolist()), world, rank)
+        h.set_params(intr=init_intr, view_pose=init_view)
+        o = capi.default_options()
+        o.compute_covariance = 0
+        barrier()
+        t1 = time.perf_counter()
+        s = h.solve(o)
+        barrier()
+        lm_s = time.perf_counter() - t1
+        lm = {"wall_s": lm_s, "iterations": int(s.iterations), "success": bool(s.success), "final_cost": float(s.final_cost),
+              "intr_err_max": float(np.abs(flat.intr - scene.gt_intr).max()), "views_total": world * args.views,
+              "obs_total": world * n_obs}
+
+    # ---- CPU baseline: the oracle's autodiff evaluation on a bounded sample, rank 0 only --------------
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from tests import helpers
+
+        if not os.path.exists(helpers.ORACLE_SO):
+            import subprocess
+
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        orc = helpers.load_oracle()
+        cores = os.cpu_count() or 1
+        sample_views = min(args.views, max(cores, 32))
+        d = flat.struct()
+        t_probe = orc.orc_reproj_bench_eval(C.byref(d), 0, sample_views, cores, 1)
+        reps = int(max(1, min(50, 12.0 / max(t_probe, 1e-3))))
+        secs = orc.orc_reproj_bench_eval(C.byref(d), 0, sample_views, cores, reps)
+        sample_obs = int(flat.blk_offset[sample_views])
+        cpu = {"value": sample_obs * reps / secs, "unit": "evals/s", "cores": cores, "kind": "port",
+               "sample": f"{sample_views} views x {args.grid * args.grid} pts x {reps} passes of the oracle's Jet<17> "
+                         f"autodiff residual+Jacobian, one residual block per view, {cores} threads over views"}
+
+    if rank == 0:
+        out = {
+            "metric": "residual+Jacobian evals/sec",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"pinhole+Brown-Conrady intrinsics, {args.views} views x {args.grid * args.grid} pts per GPU, fp64",
+                       "views_per_gpu": args.views, "points_per_view": args.grid * args.grid, "tangent_columns": P,
+                       "parallelism": f"views sharded over {world} GPU(s)"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "lm": lm,
+            "scene_gen_s": t_gen,
+        }
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

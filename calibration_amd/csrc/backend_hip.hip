@@ -1,0 +1,505 @@
+// backend_hip.hip — the HIP implementation of cba::Backend (lm_core.hpp) on an Engine, plus the
+// collective glue (host callback or RCCL over xGMI).
+//
+// Kernels here are the O(#views) / O(#blocks) part of one LM step:
+//   k_weights        rho'(s_b) per residual block (ceres HuberLoss + corrector)
+//   k_cam_partial    weighted per-camera sums of the block normal equations (chunked, fixed order)
+//   k_schur_view     per private view: damped H_pp = L L^T, y = L^-1 g_p, Z_b = L^-1 E_b
+//   k_schur_syrk     S_schur = sum_v Z_v^T Z_v, 64x64 output tiles, 4x4 register micro-tiles
+//   k_schur_gvec     g_schur = sum_v Z_v^T y_v
+//   k_backsub        delta_p, trial poses, step norms
+//   k_model          per-block model-cost terms
+// All reductions are two-stage with a fixed summation order (no atomics on fp64), so runs are
+// bitwise reproducible and 1/2/4/8-rank runs differ only by the all-reduce's own rounding.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "engine.hpp"
+#include "lm_core.hpp"
+#include "schur_math.hpp"
+
+namespace cba {
+
+constexpr int VCHUNK = 32;   // views per syrk / gvec workgroup
+constexpr int CCHUNK = 128;  // blocks per camera-sum chunk
+
+__global__ void k_weights(int n_blocks, int NACC, int s_idx, const double* __restrict__ blk_acc, double huber_delta,
+                          double* __restrict__ blk_w, double* __restrict__ blk_s) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const double s = blk_acc[static_cast<int64_t>(b) * NACC + s_idx];
+    double rho, w;
+    huber(s, huber_delta, &rho, &w);
+    blk_w[b] = w;
+    blk_s[b] = s;
+}
+
+// partial[k][e] = sum over chunk k's blocks (in list order) of w_b * acc[b][e]
+__global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ cam_blk,
+                              const double* __restrict__ blk_w, const double* __restrict__ blk_acc,
+                              double* __restrict__ partial) {
+    const int k = blockIdx.x;
+    const int64_t p0 = chunk_off[k], p1 = chunk_off[k + 1];
+    for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
+        double s = 0.0;
+        for (int64_t p = p0; p < p1; ++p) {
+            const int b = cam_blk[p];
+            s += blk_w[b] * blk_acc[static_cast<int64_t>(b) * NACC + e];
+        }
+        partial[static_cast<int64_t>(k) * NACC + e] = s;
+    }
+}
+
+// out[o][e] = sum_{t in [seg[o], seg[o+1])} rows[t][e]   (fixed order)
+__global__ void k_seg_sum(int n_out, int width, const int64_t* __restrict__ seg, const double* __restrict__ rows,
+                          double* __restrict__ out) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= static_cast<int64_t>(n_out) * width) return;
+    const int o = static_cast<int>(idx / width);
+    const int e = static_cast<int>(idx % width);
+    double s = 0.0;
+    for (int64_t t = seg[o]; t < seg[o + 1]; ++t) s += rows[t * width + e];
+    out[idx] = s;
+}
+
+// out[e] = sum_{t < n_rows} rows[t][e]
+__global__ void k_row_sum(int64_t n_rows, int64_t width, const double* __restrict__ rows, double* __restrict__ out) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= width) return;
+    double s = 0.0;
+    for (int64_t t = 0; t < n_rows; ++t) s += rows[t * width + e];
+    out[e] = s;
+}
+
+// single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4), out[w] = max_i aux[i] (if aux)
+__global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
+                                                    double* __restrict__ out) {
+    __shared__ double sh[5][256];
+    double acc[4] = {0, 0, 0, 0}, mx = 0.0;
+    for (int i = static_cast<int>(threadIdx.x); i < n; i += 256) {
+        for (int c = 0; c < w; ++c) acc[c] += in[static_cast<int64_t>(i) * w + c];
+        if (aux) mx = fmax(mx, aux[i]);
+    }
+    for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] = acc[c];
+    sh[4][threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) {
+            for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+            sh[4][threadIdx.x] = fmax(sh[4][threadIdx.x], sh[4][threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < w; ++c) out[c] = sh[c][0];
+        out[w] = sh[4][0];
+    }
+}
+
+__global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
+                             const double* __restrict__ blk_acc, const double* __restrict__ blk_w,
+                             const int32_t* __restrict__ fixed, double radius, int init_scale, int constrained,
+                             const double* __restrict__ view, double* __restrict__ scale2, double* __restrict__ L,
+                             double* __restrict__ y, double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
+                             double* __restrict__ gmax, int* __restrict__ nfail) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_views) return;
+    const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
+    double gm = 0.0;
+    const bool ok = schur_view_body(d, nb, link_blk + link_off[v], blk_acc, blk_w, fixed[v] != 0, radius, init_scale != 0,
+                                    constrained != 0, view + 7 * static_cast<int64_t>(v), scale2 + 6 * static_cast<int64_t>(v),
+                                    L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
+                                    gp + 6 * static_cast<int64_t>(v), blk_Z, &gm);
+    gmax[v] = ok ? gm : 0.0;
+    if (!ok) atomicAdd(nfail, 1);
+}
+
+__device__ __forceinline__ double z_entry(const SchurDims& d, const int32_t* __restrict__ view_cam_blk,
+                                          const double* __restrict__ blk_Z, int v, int g, int k, int nsh) {
+    if (g >= nsh) return 0.0;
+    const int cam = g / d.PC, lc = g - cam * d.PC;
+    const int b = view_cam_blk[static_cast<int64_t>(v) * d.n_cams + cam];
+    return b < 0 ? 0.0 : blk_Z[(static_cast<int64_t>(b) * 6 + k) * d.PSH + lc];
+}
+
+// grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
+// partial[chunk][pair][64*64]
+__global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, int nsh, int n_tiles,
+                                                    const int32_t* __restrict__ view_cam_blk,
+                                                    const double* __restrict__ blk_Z, double* __restrict__ partial) {
+    __shared__ double Zi[6][64], Zj[6][64];
+    // decode the upper-triangular tile pair
+    int pair = blockIdx.y, ti = 0;
+    while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
+    const int tj = ti + pair;
+    const int i0 = ti * 64, j0 = tj * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    const int v0 = blockIdx.x * VCHUNK;
+    const int v1 = min(n_views, v0 + VCHUNK);
+    for (int v = v0; v < v1; ++v) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 768; idx += 256) {
+            const int which = idx / 384, rem = idx - which * 384;
+            const int k = rem >> 6, c = rem & 63;
+            const double val = z_entry(d, view_cam_blk, blk_Z, v, (which ? j0 : i0) + c, k, nsh);
+            if (which) Zj[k][c] = val; else Zi[k][c] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[q] = Zi[k][ty * 4 + q]; b[q] = Zj[k][tx * 4 + q]; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+        }
+    }
+    double* out = partial + (static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * 4096;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
+}
+
+// partial[chunk][g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k]
+__global__ void k_schur_gvec(SchurDims d, int n_views, int nsh, const int32_t* __restrict__ view_cam_blk,
+                             const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
+    const int v0 = blockIdx.x * VCHUNK;
+    const int v1 = min(n_views, v0 + VCHUNK);
+    for (int g = threadIdx.x; g < nsh; g += blockDim.x) {
+        double s = 0.0;
+        for (int v = v0; v < v1; ++v)
+            for (int k = 0; k < 6; ++k) s += z_entry(d, view_cam_blk, blk_Z, v, g, k, nsh) * y[6 * static_cast<int64_t>(v) + k];
+        partial[static_cast<int64_t>(blockIdx.x) * nsh + g] = s;
+    }
+}
+
+__global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
+                          const int32_t* __restrict__ blk_cam, const double* __restrict__ blk_Z,
+                          const double* __restrict__ delta_sh, const int32_t* __restrict__ fixed, const double* __restrict__ L,
+                          const double* __restrict__ y, const double* __restrict__ x, double* __restrict__ delta_p,
+                          double* __restrict__ xt, double* __restrict__ stats /*[n_views][2]*/) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_views) return;
+    const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
+    double s2, x2;
+    backsub_view_body(d, nb, link_blk + link_off[v], blk_cam, blk_Z, delta_sh, fixed[v] != 0, L + 36 * static_cast<int64_t>(v),
+                      y + 6 * static_cast<int64_t>(v), x + 7 * static_cast<int64_t>(v), delta_p + 6 * static_cast<int64_t>(v),
+                      xt + 7 * static_cast<int64_t>(v), &s2, &x2);
+    stats[2 * static_cast<int64_t>(v)] = s2;
+    stats[2 * static_cast<int64_t>(v) + 1] = x2;
+}
+
+__global__ void k_model(SchurDims d, int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
+                        const double* __restrict__ blk_acc, const double* __restrict__ blk_w,
+                        const double* __restrict__ delta_p, const double* __restrict__ delta_sh,
+                        double* __restrict__ out /*[n_blocks][2]*/) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    double gd, dHd;
+    const double* dp = d.chain == CH_BUNDLE ? nullptr : delta_p + 6 * static_cast<int64_t>(blk_view[b]);
+    model_block_body(d, blk_cam[b], blk_acc + static_cast<int64_t>(b) * d.NACC, blk_w[b], dp, delta_sh, &gd, &dHd);
+    out[2 * static_cast<int64_t>(b)] = gd;
+    out[2 * static_cast<int64_t>(b) + 1] = dHd;
+}
+
+static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(std::max<int64_t>(1, (n + per - 1) / per)); }
+
+// ---- Backend on an Engine ------------------------------------------------------------------------
+struct HipLMState {
+    Structure s;
+    SchurDims dims;
+    int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
+    DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
+    DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
+    DevBuf<int32_t> link_blk;
+    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, blk_model, syrk_partial, syrk_out, gvec_partial, gvec_out,
+        small_out;
+};
+
+struct HipBackend final : Backend {
+    Engine& e;
+    HipLMState& st;
+    explicit HipBackend(Engine& eng, HipLMState& s) : e(eng), st(s) {}
+
+    void set_view_fixed(const std::vector<int32_t>& f) override {
+        if (!f.empty()) e.view_fixed.upload(f.data(), f.size(), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
+    void upload_shared(int which, const double* intr, const double* cam, const double* target) override {
+        e.intr[which].upload(intr, e.h_intr.size(), e.stream);
+        if (e.chain != CBA_CHAIN_INTRINSIC) e.cam[which].upload(cam, e.h_cam.size(), e.stream);
+        if (e.chain == CBA_CHAIN_BUNDLE) e.target[which].upload(target, 7, e.stream);
+        // pageable host memory: the copy has been staged when the call returns
+    }
+    void normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) override {
+        const Structure& s = st.s;
+        cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
+        cost2[0] = cost2[1] = 0.0;
+        if (s.n_blocks == 0) return;
+        launch_block_consts(e, 0);
+        launch_normal_eq(e);
+        hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
+                           e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
+        hipLaunchKernelGGL(k_cam_partial, dim3(std::max(1, st.n_cchunks)), dim3(256), 0, e.stream, s.NACC, st.cchunk_off.p,
+                           st.cam_blk.p, e.blk_w.p, e.blk_acc.p, st.cam_partial.p);
+        hipLaunchKernelGGL(k_seg_sum, dim3(nblk(static_cast<int64_t>(s.n_cams) * s.NACC, 256)), dim3(256), 0, e.stream, s.n_cams,
+                           s.NACC, st.cam_seg.p, st.cam_partial.p, e.cam_acc.p);
+        launch_cost(e, huber);
+        CBA_HIP(hipGetLastError());
+        cam_acc.resize(static_cast<size_t>(s.n_cams) * s.NACC);
+        e.cam_acc.download(cam_acc.data(), cam_acc.size(), e.stream);
+        e.scalar_out.download(cost2, 2, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
+    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
+               int* nfail) override {
+        const Structure& s = st.s;
+        const int n = s.nsh;
+        S.assign(static_cast<size_t>(n) * n, 0.0);
+        g.assign(n, 0.0);
+        *gmax_priv = 0.0;
+        *nfail = 0;
+        if (s.n_views == 0) return;
+        CBA_HIP(hipMemsetAsync(st.nfail.p, 0, sizeof(int32_t), e.stream));
+        hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, radius, init_scale ? 1 : 0, constrained ? 1 : 0,
+                           e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
+                           st.view_gmax.p, st.nfail.p);
+        hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
+                           st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
+        const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
+        hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, 256)), dim3(256), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
+                           st.syrk_partial.p, st.syrk_out.p);
+        hipLaunchKernelGGL(k_schur_gvec, dim3(st.n_vchunks), dim3(128), 0, e.stream, st.dims, s.n_views, n, st.view_cam_blk.p,
+                           e.blk_Z.p, e.view_y.p, st.gvec_partial.p);
+        hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, 128)), dim3(128), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
+                           static_cast<int64_t>(n), st.gvec_partial.p, st.gvec_out.p);
+        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
+                           st.small_out.p);
+        CBA_HIP(hipGetLastError());
+        std::vector<double> tiles(static_cast<size_t>(sw));
+        st.syrk_out.download(tiles.data(), tiles.size(), e.stream);
+        st.gvec_out.download(g.data(), g.size(), e.stream);
+        double gm = 0.0;
+        int32_t nf = 0;
+        st.small_out.download(&gm, 1, e.stream);
+        st.nfail.download(&nf, 1, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        *gmax_priv = gm;
+        *nfail = nf;
+        int pair = 0;
+        for (int ti = 0; ti < st.n_tiles; ++ti)
+            for (int tj = ti; tj < st.n_tiles; ++tj, ++pair) {
+                const double* T = &tiles[static_cast<size_t>(pair) * 4096];
+                for (int a = 0; a < 64; ++a) {
+                    const int i = ti * 64 + a;
+                    if (i >= n) break;
+                    for (int b = 0; b < 64; ++b) {
+                        const int j = tj * 64 + b;
+                        if (j >= n) break;
+                        S[static_cast<size_t>(i) * n + j] = T[a * 64 + b];
+                        S[static_cast<size_t>(j) * n + i] = T[a * 64 + b];
+                    }
+                }
+            }
+    }
+    void trial(const double* delta_sh, double huber, TrialStats* out) override {
+        const Structure& s = st.s;
+        *out = TrialStats();
+        if (s.n_blocks == 0) return;
+        e.delta_sh.upload(delta_sh, s.nsh, e.stream);
+        if (s.n_views > 0) {
+            hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                               st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
+                               e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 2, st.view_stats.p,
+                               static_cast<const double*>(nullptr), st.small_out.p + 8);
+        }
+        hipLaunchKernelGGL(k_model, dim3(nblk(s.n_blocks, 128)), dim3(128), 0, e.stream, st.dims, s.n_blocks, e.d_blk_cam.p,
+                           e.d_blk_view.p, e.blk_acc.p, e.blk_w.p, st.view_delta.p, e.delta_sh.p, st.blk_model.p);
+        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_blocks, 2, st.blk_model.p,
+                           static_cast<const double*>(nullptr), st.small_out.p + 16);
+        // cost at the trial point (Mode R); blk_s / blk_w of the ACCEPTED point stay in blk_acc / blk_w
+        launch_block_consts(e, 1);
+        launch_resid_trial(e, huber);
+        CBA_HIP(hipGetLastError());
+        double h[24] = {0};
+        st.small_out.download(h, 24, e.stream);
+        double c2[2];
+        e.scalar_out.download(c2, 2, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        out->step2 = s.n_views > 0 ? h[8] : 0.0;
+        out->xnorm2 = s.n_views > 0 ? h[9] : 0.0;
+        out->gd = h[16];
+        out->dHd = h[17];
+        out->cost = c2[0];
+    }
+    void launch_resid_trial(Engine& eng, double huber) {
+        // Mode R writes blk_s; keep the accepted point's s_b (needed by nobody after k_weights) simple:
+        launch_resid(eng);
+        launch_cost(eng, huber);
+    }
+    void accept() override {
+        if (!e.h_view.empty())
+            CBA_HIP(hipMemcpyAsync(e.view[0].p, e.view[1].p, sizeof(double) * e.h_view.size(), hipMemcpyDeviceToDevice, e.stream));
+    }
+    void download_private(double* view_pose) override {
+        if (e.h_view.empty()) return;
+        e.view[0].download(view_pose, e.h_view.size(), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
+    void download_blocks(std::vector<double>& acc, std::vector<double>& w) override {
+        acc.resize(static_cast<size_t>(e.n_blocks) * e.NACC);
+        w.resize(e.n_blocks);
+        e.blk_acc.download(acc.data(), acc.size(), e.stream);
+        e.blk_w.download(w.data(), w.size(), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
+};
+
+// ---- engine glue -----------------------------------------------------------------------------------
+static HipLMState* lm_state(Engine& e) { return reinterpret_cast<HipLMState*>(e.lm_state); }
+
+void destroy_lm_state(Engine& e) {
+    delete lm_state(e);
+    e.lm_state = nullptr;
+}
+
+void init_lm_state(Engine& e, const cba_reproj_problem& d) {
+    auto* st = new HipLMState();
+    e.lm_state = st;
+    build_structure(d, st->s);
+    const Structure& s = st->s;
+    st->dims = SchurDims{s.PL, s.NH, s.NACC, s.PSH, s.PC, s.n_cams, s.chain};
+    st->n_vchunks = std::max(1, (s.n_views + VCHUNK - 1) / VCHUNK);
+    st->n_tiles = (s.nsh + 63) / 64;
+    st->n_pairs = st->n_tiles * (st->n_tiles + 1) / 2;
+    // camera chunks
+    std::vector<int64_t> coff{0}, cseg(s.n_cams + 1, 0);
+    for (int c = 0; c < s.n_cams; ++c) {
+        for (int64_t p = s.cam_off[c]; p < s.cam_off[c + 1]; p += CCHUNK) coff.push_back(std::min<int64_t>(p + CCHUNK, s.cam_off[c + 1]));
+        cseg[c + 1] = static_cast<int64_t>(coff.size()) - 1;
+    }
+    st->n_cchunks = static_cast<int>(coff.size()) - 1;
+    auto up64 = [&](DevBuf<int64_t>& b, const std::vector<int64_t>& v) { b.alloc(v.size()); b.upload(v.data(), v.size(), e.stream); };
+    auto up32 = [&](DevBuf<int32_t>& b, const std::vector<int32_t>& v) { b.alloc(v.size()); b.upload(v.data(), v.size(), e.stream); };
+    up64(st->cchunk_off, coff);
+    up64(st->cam_seg, cseg);
+    up32(st->cam_blk, s.cam_blk);
+    up64(st->link_off, s.link_off);
+    up32(st->link_blk, s.link_blk);
+    up32(st->view_cam_blk, s.view_cam_blk);
+    st->nfail.alloc(1);
+    st->cam_partial.alloc(static_cast<size_t>(std::max(1, st->n_cchunks)) * s.NACC);
+    const size_t nv = std::max(1, s.n_views);
+    st->view_gmax.alloc(nv);
+    st->view_delta.alloc(nv * 6);
+    st->view_delta.zero(e.stream);
+    st->view_stats.alloc(nv * 2);
+    st->blk_model.alloc(static_cast<size_t>(std::max(1, s.n_blocks)) * 2);
+    st->syrk_partial.alloc(static_cast<size_t>(st->n_vchunks) * st->n_pairs * 4096);
+    st->syrk_out.alloc(static_cast<size_t>(st->n_pairs) * 4096);
+    st->gvec_partial.alloc(static_cast<size_t>(st->n_vchunks) * s.nsh);
+    st->gvec_out.alloc(s.nsh);
+    st->small_out.alloc(32);
+    st->small_out.zero(e.stream);
+    e.blk_w.alloc(std::max(1, s.n_blocks));
+    e.cam_acc.alloc(static_cast<size_t>(s.n_cams) * s.NACC);
+    e.view_L.alloc(nv * 36);
+    e.view_y.alloc(nv * 6);
+    e.view_D.alloc(nv * 6);
+    e.view_gp.alloc(nv * 6);
+    e.view_scale2.alloc(nv * 6);
+    e.view_fixed.alloc(nv);
+    e.view_fixed.zero(e.stream);
+    e.blk_Z.alloc(static_cast<size_t>(std::max(1, s.n_blocks)) * 6 * s.PSH);
+    e.blk_Z.zero(e.stream);
+    e.delta_sh.alloc(s.nsh);
+    CBA_HIP(hipStreamSynchronize(e.stream));
+}
+
+void engine_allreduce(Engine& e, double* buf, int64_t n) {
+    if (n <= 0) return;
+    if (e.rccl_comm) {
+        if (e.coll_buf.n < static_cast<size_t>(n)) e.coll_buf.alloc(static_cast<size_t>(n) * 2);
+        e.coll_buf.upload(buf, static_cast<size_t>(n), e.stream);
+        const ncclResult_t r = ncclAllReduce(e.coll_buf.p, e.coll_buf.p, static_cast<size_t>(n), ncclDouble, ncclSum,
+                                             reinterpret_cast<ncclComm_t>(e.rccl_comm), e.stream);
+        if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        e.coll_buf.download(buf, static_cast<size_t>(n), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    } else if (e.allreduce) {
+        if (e.allreduce(buf, n, e.allreduce_user) != 0) throw std::runtime_error("allreduce callback failed");
+    }
+}
+
+void rccl_unique_id(uint8_t* id) {
+    static_assert(sizeof(ncclUniqueId) == CBA_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    const ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) throw HipError(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memcpy(id, &u, sizeof(u));
+}
+
+void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank) {
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+    rccl_destroy(e);
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm;
+    const ncclResult_t r = ncclCommInitRank(&comm, n_ranks, u, rank);
+    if (r != ncclSuccess) throw HipError(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    e.rccl_comm = comm;
+    e.n_ranks = n_ranks;
+    e.rank = rank;
+}
+
+void rccl_destroy(Engine& e) {
+    if (e.rccl_comm) {
+        (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(e.rccl_comm));
+        e.rccl_comm = nullptr;
+    }
+}
+
+static LMDriver make_driver(Engine& e, HipBackend& be) {
+    AllReduce ar = [&e](double* buf, int64_t n) { engine_allreduce(e, buf, n); };
+    return LMDriver(lm_state(e)->s, be, e.h_intr, e.h_cam, e.h_view, e.h_target, ar, e.n_ranks, e.rank);
+}
+
+void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
+    HipBackend be(e, *lm_state(e));
+    LMDriver drv = make_driver(e, be);
+    drv.solve(o, out);
+    // leave copy 0 on the device equal to the host state
+    e.intr[0].upload(e.h_intr.data(), e.h_intr.size(), e.stream);
+    CBA_HIP(hipStreamSynchronize(e.stream));
+}
+
+int64_t covariance_dim(const Engine& e) {
+    int64_t n = static_cast<int64_t>(e.n_cams) * e.PI;
+    if (e.chain != CBA_CHAIN_INTRINSIC) n += 7LL * e.n_cams;
+    if (e.chain != CBA_CHAIN_BUNDLE) n += 7LL * e.n_views;
+    else n += 7;
+    return n;
+}
+
+void compute_covariance(Engine& e, const cba_options& o, double* cov) {
+    HipBackend be(e, *lm_state(e));
+    LMDriver drv = make_driver(e, be);
+    drv.covariance(o, cov);
+}
+
+void handeye_solve(int, const double*, const double*, double*, const cba_options*, cba_summary*, double*, int) {
+    throw std::runtime_error("cba_optimize_handeye: AX=XB kernel not built yet");
+}
+
+}  // namespace cba

@@ -1,0 +1,494 @@
+// capi.cpp — the extern "C" boundary of libcalibba.so (include/calibba.h).
+//
+// Host-side duties only: validate like the reference, lay observations out in padded SoA, build the
+// wave-tile tables, move buffers, launch kernels, translate C++ exceptions into status codes.
+// There is no CPU arithmetic path: without a HIP device every compute call returns
+// CBA_ERR_NO_DEVICE.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "engine.hpp"
+#include "structure.hpp"
+
+using namespace cba;
+
+static thread_local std::string g_err;
+
+template <typename F>
+static cba_status guarded(F&& f) {
+    try {
+        f();
+        return CBA_OK;
+    } catch (const std::invalid_argument& e) {
+        g_err = e.what();
+        return CBA_ERR_INVALID_ARGUMENT;
+    } catch (const NoDevice& e) {
+        g_err = e.what();
+        return CBA_ERR_NO_DEVICE;
+    } catch (const HipError& e) {
+        g_err = e.what();
+        return CBA_ERR_HIP;
+    } catch (const std::runtime_error& e) {
+        g_err = e.what();
+        return CBA_ERR_RUNTIME;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return CBA_ERR_INTERNAL;
+    }
+}
+
+static int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+Engine::~Engine() {
+    rccl_destroy(*this);
+    destroy_lm_state(*this);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+static Engine* as_engine(cba_reproj* h) {
+    if (!h) throw std::invalid_argument("null handle");
+    return reinterpret_cast<Engine*>(h);
+}
+
+static void upload_params(Engine& e) {
+    e.intr[0].upload(e.h_intr.data(), e.h_intr.size(), e.stream);
+    e.cam[0].upload(e.h_cam.data(), e.h_cam.size(), e.stream);
+    if (!e.h_view.empty()) e.view[0].upload(e.h_view.data(), e.h_view.size(), e.stream);
+    e.target[0].upload(e.h_target.data(), e.h_target.size(), e.stream);
+}
+
+static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
+    Structure st;
+    build_structure(d, st);  // validation mirroring the reference (SURVEY.md §8b "Errors")
+    e.chain = st.chain; e.model = st.model;
+    e.PI = st.PI; e.PL = st.PL; e.NACC = st.NACC;
+    e.n_blocks = st.n_blocks; e.n_cams = st.n_cams; e.n_views = st.n_views;
+    e.first_view_global = st.first_view_global;
+    e.blk_offset = st.blk_offset; e.blk_cam = st.blk_cam; e.blk_view = st.blk_view;
+    e.pad_offset.resize(d.n_blocks + 1);
+    int64_t pad = 0;
+    for (int b = 0; b < d.n_blocks; ++b) {
+        e.pad_offset[b] = pad;
+        pad += (e.blk_offset[b + 1] - e.blk_offset[b] + 1) & ~int64_t(1);
+    }
+    e.pad_offset[d.n_blocks] = pad;
+    e.n_obs = st.n_obs;
+    e.ld = (pad + 255) & ~int64_t(255);
+    if (e.ld == 0) e.ld = 256;
+
+    const int ndev = device_count();
+    if (ndev <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    e.device = device;
+    CBA_HIP(hipSetDevice(device));
+    CBA_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    CBA_HIP(hipEventCreate(&e.ev0));
+    CBA_HIP(hipEventCreate(&e.ev1));
+
+    // ---- observations: padded SoA --------------------------------------------------------------
+    {
+        std::vector<double> buf(static_cast<size_t>(e.ld));
+        const double* src[4] = {d.X, d.Y, d.u, d.v};
+        DevBuf<double>* dst[4] = {&e.X, &e.Y, &e.u, &e.v};
+        for (int a = 0; a < 4; ++a) {
+            std::fill(buf.begin(), buf.end(), 0.0);
+            for (int b = 0; b < d.n_blocks; ++b)
+                std::memcpy(&buf[e.pad_offset[b]], src[a] + e.blk_offset[b],
+                            sizeof(double) * static_cast<size_t>(e.blk_offset[b + 1] - e.blk_offset[b]));
+            dst[a]->alloc(e.ld);
+            dst[a]->upload(buf.data(), buf.size(), e.stream);
+            CBA_HIP(hipStreamSynchronize(e.stream));
+        }
+    }
+    // ---- tile tables ----------------------------------------------------------------------------
+    {
+        std::vector<Tile> ta, tb;
+        e.blk_tile_off.assign(d.n_blocks + 1, 0);
+        for (int b = 0; b < d.n_blocks; ++b) {
+            const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
+            const int64_t np = (n + 1) & ~int64_t(1);
+            for (int64_t s = 0; s < np; s += TILE_A)
+                ta.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_A, np - s)), e.pad_offset[b] + s});
+            e.blk_tile_off[b] = static_cast<int64_t>(tb.size());
+            for (int64_t s = 0; s < n; s += TILE_B)
+                tb.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_B, n - s)), e.pad_offset[b] + s});
+        }
+        e.blk_tile_off[d.n_blocks] = static_cast<int64_t>(tb.size());
+        e.n_tilesA = static_cast<int64_t>(ta.size());
+        e.n_tilesB = static_cast<int64_t>(tb.size());
+        e.tilesA.alloc(ta.size()); e.tilesA.upload(ta.data(), ta.size(), e.stream);
+        e.tilesB.alloc(tb.size()); e.tilesB.upload(tb.data(), tb.size(), e.stream);
+        e.d_blk_tile_off.alloc(e.blk_tile_off.size());
+        e.d_blk_tile_off.upload(e.blk_tile_off.data(), e.blk_tile_off.size(), e.stream);
+        e.d_blk_cam.alloc(d.n_blocks); e.d_blk_cam.upload(e.blk_cam.data(), e.blk_cam.size(), e.stream);
+        e.d_blk_view.alloc(d.n_blocks); e.d_blk_view.upload(e.blk_view.data(), e.blk_view.size(), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
+    // ---- parameters -----------------------------------------------------------------------------
+    e.h_intr.assign(d.intr, d.intr + static_cast<size_t>(d.n_cams) * e.PI);
+    e.h_cam.assign(7 * static_cast<size_t>(d.n_cams), 0.0);
+    e.h_target.assign(7, 0.0);
+    if (d.chain != CBA_CHAIN_INTRINSIC) e.h_cam.assign(d.cam_pose, d.cam_pose + 7 * static_cast<size_t>(d.n_cams));
+    if (d.chain != CBA_CHAIN_BUNDLE && d.n_views > 0) e.h_view.assign(d.view_pose, d.view_pose + 7 * static_cast<size_t>(d.n_views));
+    if (d.chain == CBA_CHAIN_BUNDLE) e.h_target.assign(d.target_pose, d.target_pose + 7);
+    for (int k = 0; k < 2; ++k) {
+        e.intr[k].alloc(e.h_intr.size());
+        e.cam[k].alloc(e.h_cam.size());
+        e.view[k].alloc(std::max<size_t>(e.h_view.size(), 7));
+        e.target[k].alloc(7);
+    }
+    upload_params(e);
+    e.bc.alloc(static_cast<size_t>(d.n_blocks) * 36);
+    e.sd.alloc(static_cast<size_t>(d.n_cams) * 36);
+    e.sd.zero(e.stream);
+    e.aux.alloc(static_cast<size_t>(d.n_blocks) * 12);
+    if (d.chain == CBA_CHAIN_BUNDLE) e.aux.upload(d.blk_b_T_g, static_cast<size_t>(d.n_blocks) * 12, e.stream);
+    e.partial.alloc(static_cast<size_t>(e.n_tilesB) * e.NACC);
+    e.blk_acc.alloc(static_cast<size_t>(d.n_blocks) * e.NACC);
+    e.blk_s.alloc(d.n_blocks);
+    e.scalar_out.alloc(8);
+    CBA_HIP(hipStreamSynchronize(e.stream));
+    init_lm_state(e, d);
+}
+
+extern "C" {
+
+const char* cba_version(void) { return CBA_VERSION_STRING; }
+const char* cba_last_error(void) { return g_err.c_str(); }
+int32_t cba_device_count(void) { return device_count(); }
+
+void cba_options_default(cba_options* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->optimizer = 0;
+    o->max_iterations = 1000;  // optimize.h:26
+    o->huber_delta = 1.0;      // optimize.h:28
+    o->epsilon = 1e-9;         // optimize.h:25
+    o->compute_covariance = 1;
+    o->verbose = 0;
+    o->optimize_intrinsics = 1;
+    o->optimize_skew = 0;
+    o->optimize_extrinsics = 1;
+    o->optimize_target_pose = 1;
+}
+
+int32_t cba_intrinsics_size(int32_t camera_model) { return camera_model == CBA_CAMERA_SCHEIMPFLUG ? 12 : 10; }
+int32_t cba_local_columns(int32_t chain, int32_t camera_model) {
+    return (chain == CBA_CHAIN_INTRINSIC ? 6 : 12) + cba_intrinsics_size(camera_model);
+}
+
+// Eigen::Quaterniond(Matrix3d) (third-party; restated) — populate_quat_tran, observationutils.h:43-48
+void cba_pose_from_matrix(const double* m, double* p) {
+    auto M = [&](int r, int c) { return m[c * 4 + r]; };  // column-major 4x4
+    double q[4];
+    double t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (M(2, 1) - M(1, 2)) * t;
+        q[2] = (M(0, 2) - M(2, 0)) * t;
+        q[3] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (M(k, j) - M(j, k)) * t;
+        q[1 + j] = (M(j, i) + M(i, j)) * t;
+        q[1 + k] = (M(k, i) + M(i, k)) * t;
+    }
+    for (int i = 0; i < 4; ++i) p[i] = q[i];
+    p[4] = M(0, 3); p[5] = M(1, 3); p[6] = M(2, 3);
+}
+
+// restore_pose, observationutils.h:50-62 (normalise, then Eigen toRotationMatrix)
+void cba_pose_to_matrix(const double* p, double* m) {
+    const double n = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    const double w = p[0] / n, x = p[1] / n, y = p[2] / n, z = p[3] / n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                 tyz = tz * y, tzz = tz * z;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
+                         txz - twy, tyz + twx, 1 - (txx + tyy)};
+    for (int i = 0; i < 16; ++i) m[i] = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) m[c * 4 + r] = R[3 * r + c];
+    m[12] = p[4]; m[13] = p[5]; m[14] = p[6]; m[15] = 1.0;
+}
+
+cba_status cba_reproj_create(const cba_reproj_problem* desc, int32_t device, cba_reproj** out) {
+    return guarded([&] {
+        if (!desc || !out) throw std::invalid_argument("null argument");
+        auto e = std::make_unique<Engine>();
+        build_engine(*desc, device, *e);
+        *out = reinterpret_cast<cba_reproj*>(e.release());
+    });
+}
+
+void cba_reproj_destroy(cba_reproj* h) {
+    if (!h) return;
+    Engine* e = reinterpret_cast<Engine*>(h);
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+cba_status cba_reproj_set_params(cba_reproj* h, const double* intr, const double* cam_pose, const double* view_pose,
+                                 const double* target_pose) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        if (intr) std::memcpy(e.h_intr.data(), intr, sizeof(double) * e.h_intr.size());
+        if (cam_pose && e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(e.h_cam.data(), cam_pose, sizeof(double) * e.h_cam.size());
+        if (view_pose && !e.h_view.empty()) std::memcpy(e.h_view.data(), view_pose, sizeof(double) * e.h_view.size());
+        if (target_pose && e.chain == CBA_CHAIN_BUNDLE) std::memcpy(e.h_target.data(), target_pose, sizeof(double) * 7);
+        upload_params(e);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, double* view_pose, double* target_pose) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (intr) std::memcpy(intr, e.h_intr.data(), sizeof(double) * e.h_intr.size());
+        if (cam_pose && e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(cam_pose, e.h_cam.data(), sizeof(double) * e.h_cam.size());
+        if (view_pose && !e.h_view.empty()) std::memcpy(view_pose, e.h_view.data(), sizeof(double) * e.h_view.size());
+        if (target_pose && e.chain == CBA_CHAIN_BUNDLE) std::memcpy(target_pose, e.h_target.data(), sizeof(double) * 7);
+    });
+}
+
+int64_t cba_reproj_num_observations(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->n_obs : 0; }
+
+static void ensure_eval_buffers(Engine& e) {
+    if (e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
+    if (e.J.n < static_cast<size_t>(2 * e.PL) * e.ld) e.J.alloc(static_cast<size_t>(2 * e.PL) * e.ld);
+}
+
+cba_status cba_reproj_eval(cba_reproj* h) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        ensure_eval_buffers(e);
+        launch_block_consts(e, 0);
+        launch_eval(e);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_eval) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (iters <= 0) throw std::invalid_argument("iters must be positive");
+        CBA_HIP(hipSetDevice(e.device));
+        ensure_eval_buffers(e);
+        launch_block_consts(e, 0);
+        for (int i = 0; i < warmup; ++i) launch_eval(e);
+        CBA_HIP(hipEventRecord(e.ev0, e.stream));
+        for (int i = 0; i < iters; ++i) launch_eval(e);
+        CBA_HIP(hipEventRecord(e.ev1, e.stream));
+        CBA_HIP(hipEventSynchronize(e.ev1));
+        float ms = 0.f;
+        CBA_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
+        *ms_per_eval = static_cast<double>(ms) / iters;
+    });
+}
+
+cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        if (e.r.n < static_cast<size_t>(2 * e.ld)) throw std::runtime_error("cba_reproj_eval has not been called");
+        const int P = e.PL;
+        std::vector<double> hr(static_cast<size_t>(2 * e.ld));
+        e.r.download(hr.data(), hr.size(), e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        if (r)
+            for (int b = 0; b < e.n_blocks; ++b)
+                for (int64_t i = e.blk_offset[b]; i < e.blk_offset[b + 1]; ++i) {
+                    const int64_t pi = e.pad_offset[b] + (i - e.blk_offset[b]);
+                    r[2 * i] = hr[pi];
+                    r[2 * i + 1] = hr[e.ld + pi];
+                }
+        if (J) {
+            std::vector<double> row(static_cast<size_t>(e.ld));
+            for (int k = 0; k < 2 * P; ++k) {
+                CBA_HIP(hipMemcpyAsync(row.data(), e.J.p + static_cast<size_t>(k) * e.ld, sizeof(double) * e.ld,
+                                       hipMemcpyDeviceToHost, e.stream));
+                CBA_HIP(hipStreamSynchronize(e.stream));
+                const int uvrow = k / P, col = k % P;
+                for (int b = 0; b < e.n_blocks; ++b)
+                    for (int64_t i = e.blk_offset[b]; i < e.blk_offset[b + 1]; ++i)
+                        J[(2 * i + uvrow) * P + col] = row[e.pad_offset[b] + (i - e.blk_offset[b])];
+            }
+        }
+    });
+}
+
+cba_status cba_reproj_cost(cba_reproj* h, double huber_delta, double* cost) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        launch_block_consts(e, 0);
+        launch_resid(e);
+        launch_cost(e, huber_delta);
+        double out[2];
+        e.scalar_out.download(out, 2, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        engine_allreduce(e, out, 1);
+        *cost = out[0];
+    });
+}
+
+int64_t cba_reproj_block_normal_eq_size(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->NACC : 0; }
+
+cba_status cba_reproj_block_normal_eq(cba_reproj* h, double* out) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        launch_block_consts(e, 0);
+        launch_normal_eq(e);
+        e.blk_acc.download(out, static_cast<size_t>(e.n_blocks) * e.NACC, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    });
+}
+
+cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary* summary) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (!opts || !summary) throw std::invalid_argument("null argument");
+        CBA_HIP(hipSetDevice(e.device));
+        solve_lm(e, *opts, summary);
+    });
+}
+
+int64_t cba_reproj_covariance_dim(const cba_reproj* h) { return h ? covariance_dim(*reinterpret_cast<const Engine*>(h)) : 0; }
+
+cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double* cov) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (!opts || !cov) throw std::invalid_argument("null argument");
+        CBA_HIP(hipSetDevice(e.device));
+        compute_covariance(e, *opts, cov);
+    });
+}
+
+cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+        e.allreduce = fn;
+        e.allreduce_user = user;
+        e.n_ranks = n_ranks;
+        e.rank = rank;
+    });
+}
+
+cba_status cba_rccl_unique_id(uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES]) {
+    return guarded([&] { rccl_unique_id(id); });
+}
+
+cba_status cba_reproj_init_rccl(cba_reproj* h, const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        rccl_init(e, id, n_ranks, rank);
+    });
+}
+
+// ---- one-shot entry points -----------------------------------------------------------------------
+static void one_shot(const cba_reproj_problem& d, const cba_options* opts, cba_summary* summary, double* cov) {
+    if (!opts || !summary) throw std::invalid_argument("null argument");
+    auto e = std::make_unique<Engine>();
+    build_engine(d, 0, *e);
+    solve_lm(*e, *opts, summary);
+    if (d.intr) std::memcpy(d.intr, e->h_intr.data(), sizeof(double) * e->h_intr.size());
+    if (d.cam_pose && d.chain != CBA_CHAIN_INTRINSIC) std::memcpy(d.cam_pose, e->h_cam.data(), sizeof(double) * e->h_cam.size());
+    if (d.view_pose && !e->h_view.empty()) std::memcpy(d.view_pose, e->h_view.data(), sizeof(double) * e->h_view.size());
+    if (d.target_pose && d.chain == CBA_CHAIN_BUNDLE) std::memcpy(d.target_pose, e->h_target.data(), sizeof(double) * 7);
+    if (cov && opts->compute_covariance) {
+        try {
+            compute_covariance(*e, *opts, cov);
+        } catch (const HipError&) {
+            throw;
+        } catch (const std::runtime_error&) {  // rank deficient: the reference leaves the matrix empty
+            const int64_t n = covariance_dim(*e);
+            std::memset(cov, 0, sizeof(double) * static_cast<size_t>(n * n));
+        }
+    }
+    CBA_HIP(hipStreamSynchronize(e->stream));
+}
+
+cba_status cba_optimize_intrinsics(int32_t camera_model, int32_t n_views, const int64_t* view_offset, const double* X,
+                                   const double* Y, const double* u, const double* v, double* intr, double* c_T_t,
+                                   const cba_options* opts, cba_summary* summary, double* cov) {
+    return guarded([&] {
+        if (n_views < 4)  // intrinsics.cpp:92-96
+            throw std::invalid_argument("Insufficient views for calibration (at least 4 required).");
+        cba_reproj_problem d;
+        std::memset(&d, 0, sizeof(d));
+        d.chain = CBA_CHAIN_INTRINSIC; d.camera_model = camera_model;
+        d.n_blocks = n_views; d.n_cams = 1; d.n_views = n_views;
+        d.blk_offset = view_offset; d.X = X; d.Y = Y; d.u = u; d.v = v;
+        d.intr = intr; d.view_pose = c_T_t;
+        cba_options o = *opts;
+        o.optimize_intrinsics = 1;
+        one_shot(d, &o, summary, cov);
+    });
+}
+
+cba_status cba_optimize_extrinsics(int32_t camera_model, int32_t n_cams, int32_t n_views, int32_t n_blocks,
+                                   const int64_t* blk_offset, const int32_t* blk_view, const int32_t* blk_cam,
+                                   const double* X, const double* Y, const double* u, const double* v, double* intr,
+                                   double* c_T_r, double* r_T_t, const cba_options* opts, cba_summary* summary,
+                                   double* cov) {
+    return guarded([&] {
+        cba_reproj_problem d;
+        std::memset(&d, 0, sizeof(d));
+        d.chain = CBA_CHAIN_EXTRINSIC; d.camera_model = camera_model;
+        d.n_blocks = n_blocks; d.n_cams = n_cams; d.n_views = n_views;
+        d.blk_offset = blk_offset; d.blk_view = blk_view; d.blk_cam = blk_cam;
+        d.X = X; d.Y = Y; d.u = u; d.v = v;
+        d.intr = intr; d.cam_pose = c_T_r; d.view_pose = r_T_t;
+        one_shot(d, opts, summary, cov);
+    });
+}
+
+cba_status cba_optimize_bundle(int32_t camera_model, int32_t n_cams, int32_t n_blocks, const int64_t* blk_offset,
+                               const int32_t* blk_cam, const double* blk_b_T_g, const double* X, const double* Y,
+                               const double* u, const double* v, double* intr, double* g_T_c, double* b_T_t,
+                               const cba_options* opts, cba_summary* summary, double* cov) {
+    return guarded([&] {
+        cba_reproj_problem d;
+        std::memset(&d, 0, sizeof(d));
+        d.chain = CBA_CHAIN_BUNDLE; d.camera_model = camera_model;
+        d.n_blocks = n_blocks; d.n_cams = n_cams; d.n_views = 0;
+        d.blk_offset = blk_offset; d.blk_cam = blk_cam; d.blk_b_T_g = blk_b_T_g;
+        d.X = X; d.Y = Y; d.u = u; d.v = v;
+        d.intr = intr; d.cam_pose = g_T_c; d.target_pose = b_T_t;
+        one_shot(d, opts, summary, cov);
+    });
+}
+
+cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target, double* g_T_c,
+                                const cba_options* opts, cba_summary* summary, double* cov) {
+    return guarded([&] {
+        if (!opts || !summary || !g_T_c) throw std::invalid_argument("null argument");
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        handeye_solve(n_poses, base_T_gripper, cam_T_target, g_T_c, opts, summary, cov, 0);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// engine.hpp — internal state behind the opaque cba_reproj handle.
+//
+// HBM layout (all fp64, SoA, one allocation per array):
+//   X, Y, u, v        [ld]          observations; every residual block starts at an EVEN padded index
+//                                    (so a lane's two observations are one 16-byte load/store) and ld is
+//                                    the padded total rounded up to 256 elements
+//   r                 [2][ld]       Mode A residuals (u row, v row)
+//   J                 [2*P][ld]     Mode A Jacobian: row k = column (k % P) of the u (k < P) / v row
+//   bc                [n_blocks][36] per-block chain constants (reproj_math.hpp BC_*)
+//   sd                [n_cams][36]  Scheimpflug per-camera constants (SD_*)
+//   intr/cam/view/target            parameter blocks, current [0] and trial [1] copies
+//   tilesA / tilesB                 wave-tile tables: a tile is <=128 (Mode A) / <=TILE_B (Mode B, R)
+//                                    consecutive observations of ONE block, processed by ONE wavefront
+//   partial           [n_tilesB][NACC]  per-tile Mode B sums;  blk_acc [n_blocks][NACC] per-block sums
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/calibba.h"
+
+namespace cba {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct NoDevice : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define CBA_HIP(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            throw cba::HipError(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +    \
+                                std::to_string(__LINE__) + ")");                                           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        CBA_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void upload(const T* src, size_t count, hipStream_t s) {
+        if (count) CBA_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T* dst, size_t count, hipStream_t s) const {
+        if (count) CBA_HIP(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    void zero(hipStream_t s) { CBA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+struct Tile {       // 16 bytes, read with one scalar load per wave
+    int32_t blk;    // residual block
+    int32_t count;  // observations in this tile (Mode A: padded, even; Mode B/R: valid count)
+    int64_t start;  // padded observation index of the tile's first observation
+};
+
+constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
+constexpr int OPL_B = 8;     // Mode B/R: observations per lane per tile
+constexpr int TILE_B = 64 * OPL_B;
+
+struct ViewLink {  // CSR of residual blocks per private view (Schur elimination)
+    std::vector<int64_t> off;
+    std::vector<int32_t> blk;
+};
+
+struct Engine {
+    // ---- problem -----------------------------------------------------------------------------
+    int chain = 0, model = 0;
+    int n_blocks = 0, n_cams = 0, n_views = 0;
+    int64_t first_view_global = 0;
+    int64_t n_obs = 0, ld = 0;
+    int PI = 10, PL = 16, NACC = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    std::vector<int64_t> blk_offset;  // unpadded CSR (host)
+    std::vector<int64_t> pad_offset;  // padded start of every block (host)
+    std::vector<int32_t> blk_cam, blk_view;
+    std::vector<int64_t> blk_tile_off;  // Mode B tiles per block CSR (host)
+    int64_t n_tilesA = 0, n_tilesB = 0;
+
+    // host copies of the parameters (current accepted state); h_cam / h_target are always sized
+    // (7 per camera / 7) and simply unused by chains that have no such block
+    std::vector<double> h_intr, h_cam, h_view, h_target;
+
+    // ---- device ------------------------------------------------------------------------------
+    DevBuf<double> X, Y, u, v, r, J;
+    DevBuf<double> bc, sd, aux;  // aux: bundle b_T_g [n_blocks][12]
+    DevBuf<double> intr[2], cam[2], view[2], target[2];
+    int active = 0;  // parameter copy (0 current / 1 trial) the constants bc, sd were last built from
+    DevBuf<int32_t> d_blk_cam, d_blk_view;
+    DevBuf<Tile> tilesA, tilesB;
+    DevBuf<int64_t> d_blk_tile_off;
+    DevBuf<double> partial, blk_acc, blk_s, scalar_out;
+
+    // ---- LM / Schur state (lm_host.cpp, kernels_schur.hip) ------------------------------------
+    ViewLink links;
+    DevBuf<int64_t> d_link_off;
+    DevBuf<int32_t> d_link_blk;
+    DevBuf<double> blk_w;       // [n_blocks] Huber weights rho'(s_b)
+    DevBuf<double> cam_acc;     // [n_cams][NACC] weighted per-camera sums
+    DevBuf<double> view_L;      // [n_views][21] Cholesky factor of damped H_pp
+    DevBuf<double> view_y;      // [n_views][6]
+    DevBuf<double> view_D;      // [n_views][6]  damping added to diag(H_pp)
+    DevBuf<double> view_gp;     // [n_views][6]  g_p
+    DevBuf<double> view_scale2; // [n_views][6]  jacobi scale^2
+    DevBuf<double> blk_Z;       // [n_blocks][6][PSH]
+    DevBuf<int32_t> view_fixed; // [n_views]
+    DevBuf<double> red_part, red_out, delta_sh, stats_part, stats_out;
+    int n_red_chunks = 0;
+
+    // ---- collectives -------------------------------------------------------------------------
+    cba_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    DevBuf<double> coll_buf;
+    void* lm_state = nullptr;  // HipLMState (backend_hip.hip)
+
+    ~Engine();
+};
+
+// kernels_reproj.hip
+void launch_block_consts(Engine& e, int which);         // params[which] -> bc, sd
+void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
+void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2
+void launch_normal_eq(Engine& e);                       // Mode B: blk_acc[b] = [H | g | s]
+void launch_cost(Engine& e, double huber_delta);        // scalar_out[0] = 1/2 sum rho(blk_s)
+
+// backend_hip.hip
+void init_lm_state(Engine& e, const cba_reproj_problem& d);
+void destroy_lm_state(Engine& e);
+void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
+void compute_covariance(Engine& e, const cba_options& o, double* cov);
+int64_t covariance_dim(const Engine& e);
+void engine_allreduce(Engine& e, double* host_buf, int64_t count);
+void rccl_unique_id(uint8_t* id);
+void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank);
+void rccl_destroy(Engine& e);
+void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
+                   double* cov, int device);
+
+}  // namespace cba

@@ -1,0 +1,339 @@
+// kernels_reproj.hip — gfx950 kernels of the reprojection hot path.
+//
+//   k_block_consts / k_scheimpflug_consts   parameters -> per-block chain constants (tiny)
+//   k_eval       "Mode A": residual + tangent Jacobian of every observation, written to HBM (SoA)
+//   k_resid      "Mode R": per-tile sum of squared residuals (trial-point cost)
+//   k_normal_eq  "Mode B": per-tile J^T J / J^T r / |r|^2 accumulated in registers, wave-shuffle
+//                reduced, one partial row per tile
+//   k_tile_sum   fixed-order sum of a block's tile partials (deterministic: no atomics anywhere)
+//
+// Work decomposition: one WAVEFRONT (64 lanes) owns one tile = a run of consecutive observations
+// of a single residual block.  Everything that is constant over a block (chain matrices, camera
+// parameters) is therefore wave-uniform: the tile record is fetched with a scalar load
+// (readfirstlane'd wave index) and the constants live in SGPRs / are broadcast, while X,Y,u,v and
+// the outputs are unit-stride 16-byte-per-lane (Mode A) or 8-byte-per-lane vector accesses.
+// The arithmetic is reproj_math.hpp (shared with the CPU test build).
+#include "engine.hpp"
+#include "reproj_math.hpp"
+
+namespace cba {
+
+__device__ __forceinline__ int64_t wave_index() {
+    // wave-uniform by construction; readfirstlane lets the compiler keep it (and everything
+    // indexed by it) in scalar registers
+    return static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    // fixed butterfly => bitwise reproducible
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int CHAIN>
+__global__ void k_block_consts(int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
+                               const double* __restrict__ cam, const double* __restrict__ view,
+                               const double* __restrict__ target, const double* __restrict__ aux, double* __restrict__ bc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const double *pA, *pB = nullptr, *ax = nullptr;
+    if (CHAIN == CH_INTRINSIC) {
+        pA = view + 7 * static_cast<int64_t>(blk_view[b]);
+    } else if (CHAIN == CH_EXTRINSIC) {
+        pA = view + 7 * static_cast<int64_t>(blk_view[b]);
+        pB = cam + 7 * static_cast<int64_t>(blk_cam[b]);
+    } else {
+        pA = target;
+        pB = cam + 7 * static_cast<int64_t>(blk_cam[b]);
+        ax = aux + 12 * static_cast<int64_t>(b);
+    }
+    double out[BC_SIZE];
+    block_consts<CHAIN>(pA, pB, ax, out);
+    for (int i = 0; i < BC_SIZE; ++i) bc[static_cast<int64_t>(b) * BC_SIZE + i] = out[i];
+}
+
+__global__ void k_scheimpflug_consts(int n_cams, const double* __restrict__ intr, double* __restrict__ sd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cams) return;
+    double out[SD_SIZE];
+    for (int i = 0; i < SD_SIZE; ++i) out[i] = 0.0;
+    scheimpflug_consts(intr + 12 * static_cast<int64_t>(c), out);
+    for (int i = 0; i < SD_SIZE; ++i) sd[static_cast<int64_t>(c) * SD_SIZE + i] = out[i];
+}
+
+// ---- Mode A -----------------------------------------------------------------------------------
+// Algorithmic HBM traffic per observation: 4 loads + 2 residual stores + 2*P Jacobian stores of
+// 8 bytes = 304 B (P=16) ... 432 B (P=24).  HBM-bound: ~0.3 kFLOP per observation.
+template <int CHAIN, int MODEL>
+__global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, int64_t n_tiles,
+                                              const double* __restrict__ bc, const double* __restrict__ intr,
+                                              const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                              const double* __restrict__ X, const double* __restrict__ Y,
+                                              const double* __restrict__ u, const double* __restrict__ v,
+                                              double* __restrict__ r, double* __restrict__ J, int64_t ld) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    constexpr int PL = LocalCols<CHAIN, MODEL>::value;
+    const int64_t w = wave_index();
+    if (w >= n_tiles) return;
+    const Tile t = tiles[w];
+    const int lane = threadIdx.x & 63;
+    if (2 * lane >= t.count) return;
+    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const int cam = blk_cam[t.blk];
+    const double* ip = intr + static_cast<int64_t>(cam) * PI;
+    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+
+    const int64_t i0 = t.start + 2 * lane;
+    const double2 Xv = *reinterpret_cast<const double2*>(X + i0);
+    const double2 Yv = *reinterpret_cast<const double2*>(Y + i0);
+    const double2 uv = *reinterpret_cast<const double2*>(u + i0);
+    const double2 vv = *reinterpret_cast<const double2*>(v + i0);
+
+    double r0[2], r1[2], Ju0[PL], Jv0[PL], Ju1[PL], Jv1[PL];
+    reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.x, Yv.x, uv.x, vv.x, r0, Ju0, Jv0);
+    reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.y, Yv.y, uv.y, vv.y, r1, Ju1, Jv1);
+
+    *reinterpret_cast<double2*>(r + i0) = make_double2(r0[0], r1[0]);
+    *reinterpret_cast<double2*>(r + ld + i0) = make_double2(r0[1], r1[1]);
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+        *reinterpret_cast<double2*>(J + static_cast<int64_t>(k) * ld + i0) = make_double2(Ju0[k], Ju1[k]);
+        *reinterpret_cast<double2*>(J + static_cast<int64_t>(PL + k) * ld + i0) = make_double2(Jv0[k], Jv1[k]);
+    }
+}
+
+// ---- Mode R -----------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, int64_t n_tiles,
+                                               const double* __restrict__ bc, const double* __restrict__ intr,
+                                               const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                               const double* __restrict__ X, const double* __restrict__ Y,
+                                               const double* __restrict__ u, const double* __restrict__ v,
+                                               double* __restrict__ partial_s) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    const int64_t w = wave_index();
+    if (w >= n_tiles) return;
+    const Tile t = tiles[w];
+    const int lane = threadIdx.x & 63;
+    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const int cam = blk_cam[t.blk];
+    const double* ip = intr + static_cast<int64_t>(cam) * PI;
+    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < OPL_B; ++k) {
+        const int j = lane + 64 * k;
+        if (j < t.count) {
+            const int64_t i = t.start + j;
+            double rr[2];
+            reproj_residual<MODEL>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr);
+            s += rr[0] * rr[0] + rr[1] * rr[1];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) partial_s[w] = s;
+}
+
+// out[b][e] = sum over the block's tiles (in tile order) of partial[t][e]
+__global__ void k_tile_sum(int n_blocks, int width, const int64_t* __restrict__ blk_tile_off,
+                           const double* __restrict__ partial, double* __restrict__ out) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= static_cast<int64_t>(n_blocks) * width) return;
+    const int b = static_cast<int>(idx / width);
+    const int e = static_cast<int>(idx % width);
+    double s = 0.0;
+    for (int64_t t = blk_tile_off[b]; t < blk_tile_off[b + 1]; ++t) s += partial[t * width + e];
+    out[idx] = s;
+}
+
+// scalar_out[0] = 1/2 sum_b rho(s_b), scalar_out[1] = sum_b s_b  (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_cost(int n_blocks, const double* __restrict__ blk_s, double huber_delta,
+                                              double* __restrict__ out) {
+    __shared__ double sh[2][256];
+    double c = 0.0, ss = 0.0;
+    for (int b = static_cast<int>(threadIdx.x); b < n_blocks; b += 256) {
+        double rho, w;
+        huber(blk_s[b], huber_delta, &rho, &w);
+        c += 0.5 * rho;
+        ss += blk_s[b];
+    }
+    sh[0][threadIdx.x] = c;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; }
+}
+
+// ---- Mode B -----------------------------------------------------------------------------------
+// Per tile: H = sum J^T J (upper triangle, row-major packed), g = sum J^T r, s = sum |r|^2, all
+// UNWEIGHTED (the per-block Huber weight is a scalar applied when blocks are assembled).
+// The packed accumulator vector [H | g | s] is split round-robin over NPARTS launches so that one
+// lane's share stays in registers; every part re-evaluates the (cheap) Jacobian rows.
+template <int CHAIN, int MODEL, int NPARTS, int PART>
+__global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tiles, int64_t n_tiles,
+                                                   const double* __restrict__ bc, const double* __restrict__ intr,
+                                                   const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                                   const double* __restrict__ X, const double* __restrict__ Y,
+                                                   const double* __restrict__ u, const double* __restrict__ v,
+                                                   double* __restrict__ partial) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    constexpr int PL = LocalCols<CHAIN, MODEL>::value;
+    constexpr int NH = PL * (PL + 1) / 2;
+    constexpr int NACC = NH + PL + 1;
+    const int64_t w = wave_index();
+    if (w >= n_tiles) return;
+    const Tile t = tiles[w];
+    const int lane = threadIdx.x & 63;
+    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const int cam = blk_cam[t.blk];
+    const double* ip = intr + static_cast<int64_t>(cam) * PI;
+    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+
+    double acc[NACC];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+
+#pragma unroll 1
+    for (int k = 0; k < OPL_B; ++k) {
+        const int j = lane + 64 * k;
+        if (j < t.count) {
+            const int64_t i = t.start + j;
+            double rr[2], Ju[PL], Jv[PL];
+            reproj_point<CHAIN, MODEL>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr, Ju, Jv);
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < PL; ++a) {
+#pragma unroll
+                for (int b = a; b < PL; ++b) {
+                    if ((e % NPARTS) == PART) acc[e] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                    ++e;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < PL; ++a) {
+                if (((NH + a) % NPARTS) == PART) acc[NH + a] += Ju[a] * rr[0] + Jv[a] * rr[1];
+            }
+            if (((NH + PL) % NPARTS) == PART) acc[NH + PL] += rr[0] * rr[0] + rr[1] * rr[1];
+        }
+    }
+    double* out = partial + w * NACC;
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) {
+        if ((e % NPARTS) == PART) {
+            const double s = wave_sum(acc[e]);
+            if (lane == 0) out[e] = s;
+        }
+    }
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+#define CBA_DISPATCH(e, CALL)                                                                     \
+    switch ((e).chain * 2 + (e).model) {                                                          \
+        case 0: { CALL(CH_INTRINSIC, CAM_PINHOLE_BC) } break;                                     \
+        case 1: { CALL(CH_INTRINSIC, CAM_SCHEIMPFLUG) } break;                                    \
+        case 2: { CALL(CH_EXTRINSIC, CAM_PINHOLE_BC) } break;                                     \
+        case 3: { CALL(CH_EXTRINSIC, CAM_SCHEIMPFLUG) } break;                                    \
+        case 4: { CALL(CH_BUNDLE, CAM_PINHOLE_BC) } break;                                        \
+        case 5: { CALL(CH_BUNDLE, CAM_SCHEIMPFLUG) } break;                                       \
+        default: throw std::runtime_error("bad chain/model");                                     \
+    }
+
+static inline unsigned blocks_for(int64_t n, int per) { return static_cast<unsigned>((n + per - 1) / per); }
+
+void launch_block_consts(Engine& e, int which) {
+    e.active = which;
+    if (e.n_blocks == 0) return;
+    const unsigned g = blocks_for(e.n_blocks, 128);
+    const double* cam = e.cam[which].p;
+    const double* view = e.view[which].p;
+    const double* target = e.target[which].p;
+    switch (e.chain) {
+        case CH_INTRINSIC:
+            hipLaunchKernelGGL(k_block_consts<CH_INTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+            break;
+        case CH_EXTRINSIC:
+            hipLaunchKernelGGL(k_block_consts<CH_EXTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+            break;
+        default:
+            hipLaunchKernelGGL(k_block_consts<CH_BUNDLE>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+    }
+    if (e.model == CAM_SCHEIMPFLUG)
+        hipLaunchKernelGGL(k_scheimpflug_consts, dim3(blocks_for(e.n_cams, 64)), dim3(64), 0, e.stream, e.n_cams,
+                           e.intr[which].p, e.sd.p);
+    CBA_HIP(hipGetLastError());
+}
+
+// bc/sd were built from parameter copy e.active; the kernels read the matching intrinsics
+static const double* intr_of(Engine& e) { return e.intr[e.active].p; }
+
+void launch_eval(Engine& e) {
+    if (e.n_tilesA == 0) return;
+    const unsigned g = blocks_for(e.n_tilesA, 4);
+#define CALL(C, M)                                                                                             \
+    hipLaunchKernelGGL((k_eval<C, M>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,          \
+                       intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+    CBA_DISPATCH(e, CALL)
+#undef CALL
+    CBA_HIP(hipGetLastError());
+}
+
+void launch_resid(Engine& e) {
+    if (e.n_tilesB == 0) return;
+    const unsigned g = blocks_for(e.n_tilesB, 4);
+    if (e.model == CAM_PINHOLE_BC)
+        hipLaunchKernelGGL(k_resid<CAM_PINHOLE_BC>, dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
+    else
+        hipLaunchKernelGGL(k_resid<CAM_SCHEIMPFLUG>, dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
+    hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(e.n_blocks, 256)), dim3(256), 0, e.stream, e.n_blocks, 1,
+                       e.d_blk_tile_off.p, e.partial.p, e.blk_s.p);
+    CBA_HIP(hipGetLastError());
+}
+
+void launch_cost(Engine& e, double huber_delta) {
+    hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.scalar_out.p);
+    CBA_HIP(hipGetLastError());
+}
+
+template <int C, int M, int NP, int PART>
+static void launch_ne_part(Engine& e, unsigned g) {
+    hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
+                       intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
+}
+template <int C, int M>
+static void launch_ne(Engine& e, unsigned g) {
+    if constexpr (C == CH_INTRINSIC) {  // P = 16 / 18: 153 / 190 accumulators -> 2 parts
+        launch_ne_part<C, M, 2, 0>(e, g);
+        launch_ne_part<C, M, 2, 1>(e, g);
+    } else {  // P = 22 / 24: 276 / 325 accumulators -> 4 parts
+        launch_ne_part<C, M, 4, 0>(e, g);
+        launch_ne_part<C, M, 4, 1>(e, g);
+        launch_ne_part<C, M, 4, 2>(e, g);
+        launch_ne_part<C, M, 4, 3>(e, g);
+    }
+}
+
+void launch_normal_eq(Engine& e) {
+    if (e.n_tilesB == 0) return;
+    const unsigned g = blocks_for(e.n_tilesB, 4);
+#define CALL(C, M) launch_ne<C, M>(e, g);
+    CBA_DISPATCH(e, CALL)
+#undef CALL
+    const int64_t tot = static_cast<int64_t>(e.n_blocks) * e.NACC;
+    hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.n_blocks, e.NACC,
+                       e.d_blk_tile_off.p, e.partial.p, e.blk_acc.p);
+    CBA_HIP(hipGetLastError());
+}
+
+}  // namespace cba

@@ -1,0 +1,551 @@
+// lm_core.hpp — host Levenberg-Marquardt driver over the Schur-reduced camera system.
+//
+// Restates what the reference delegates to ceres::Solve (src/estimation/detail/ceresutils.h:27-43):
+// Ceres 2.x TrustRegionMinimizer + LevenbergMarquardtStrategy with the options the reference sets
+// (function/gradient/parameter tolerance = epsilon, max_num_iterations) and Ceres' defaults
+// (initial radius 1e4, max 1e16, min 1e-32, min_relative_decrease 1e-3, LM diagonal clamp
+// [1e-6, 1e32], jacobi_scaling, monotonic steps, 5 consecutive invalid steps -> FAILURE), the
+// per-residual-block Huber corrector, QuaternionManifold / SubsetManifold / constant blocks and the
+// fx, fy >= 0 projection.  Ceres is a third-party dependency absent from /root/reference: see
+// DESIGN.md "Solver semantics" for the restated rules and the one known deviation (no Armijo
+// line search on bounds-constrained problems).
+//
+// All O(#observations) and O(#views) arithmetic happens in the Backend (HIP kernels); this file
+// only handles the reduced system (<= a few hundred unknowns), the accept/reject control flow,
+// the shared parameter update and the one sum-all-reduce per linear solve.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+#include "dense.hpp"
+#include "reproj_math.hpp"
+#include "schur_math.hpp"
+#include "structure.hpp"
+
+namespace cba {
+
+struct TrialStats {
+    double gd = 0, dHd = 0;       // sum_b w g_b^T d, sum_b w d^T H_b d over this rank's blocks
+    double step2 = 0, xnorm2 = 0; // private (per-view) share of |x+ - x|^2 and |x|^2
+    double cost = 0;              // 1/2 sum_b rho(s_b) at the trial point, this rank's blocks
+};
+
+struct Backend {
+    virtual ~Backend() = default;
+    virtual void set_view_fixed(const std::vector<int32_t>& fixed) = 0;
+    // shared parameter copy `which` (0 current, 1 trial): intr [n_cams][PI], cam [n_cams][7], target [7]
+    virtual void upload_shared(int which, const double* intr, const double* cam, const double* target) = 0;
+    // at copy 0: block constants, Mode B normal equations, Huber weights, weighted per-camera sums
+    // cam_acc [n_cams][NACC]; cost2 = {1/2 sum rho(s_b), sum s_b}
+    virtual void normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) = 0;
+    // per-view elimination with the given radius; S_schur [nsh*nsh], g_schur [nsh] (this rank's views)
+    virtual void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g,
+                       double* gmax_priv, int* nfail) = 0;
+    // back-substitute delta_sh, write private trial poses (copy 1), model terms, trial cost
+    virtual void trial(const double* delta_sh, double huber, TrialStats* st) = 0;
+    virtual void accept() = 0;  // private copy 1 -> copy 0
+    virtual void download_private(double* view_pose) = 0;
+    virtual void download_blocks(std::vector<double>& acc, std::vector<double>& w) = 0;
+};
+
+using AllReduce = std::function<void(double*, int64_t)>;
+
+class LMDriver {
+  public:
+    LMDriver(const Structure& s, Backend& be, std::vector<double>& intr, std::vector<double>& cam,
+             std::vector<double>& view, std::vector<double>& target, AllReduce ar, int n_ranks, int rank)
+        : s_(s), be_(be), intr_(intr), cam_(cam), view_(view), target_(target), ar_(std::move(ar)), n_ranks_(n_ranks),
+          rank_(rank) {}
+
+    // ---- masks: which blocks Ceres would hold constant ----------------------------------------
+    void setup(const cba_options& o) {
+        const int n = s_.nsh;
+        active_.assign(n, 1);
+        intr_var_ = s_.chain == CBA_CHAIN_INTRINSIC ? true : o.optimize_intrinsics != 0;
+        cam_var_.assign(s_.n_cams, 0);
+        target_var_ = false;
+        std::vector<int32_t> fixed(s_.n_views, 0);
+        auto mask_intr = [&](int base) {
+            for (int k = 0; k < s_.PI; ++k) active_[base + k] = intr_var_ ? 1 : 0;
+            if (!o.optimize_skew) active_[base + 4] = 0;  // SubsetManifold({idx_skew}), pinhole.h:121
+        };
+        if (s_.chain == CBA_CHAIN_INTRINSIC) {
+            mask_intr(0);
+        } else if (s_.chain == CBA_CHAIN_EXTRINSIC) {  // extrinsics.cpp:110-150
+            for (int c = 0; c < s_.n_cams; ++c) {
+                cam_var_[c] = (o.optimize_extrinsics && c != 0) ? 1 : 0;
+                for (int k = 0; k < 6; ++k) active_[c * s_.PC + k] = cam_var_[c];
+                mask_intr(c * s_.PC + 6);
+            }
+            if (o.optimize_intrinsics && s_.n_views > 0 && s_.first_view_global == 0) fixed[0] = 1;
+        } else {  // bundle.cpp:98-131
+            target_var_ = o.optimize_target_pose != 0;
+            for (int k = 0; k < 6; ++k) active_[k] = target_var_ ? 1 : 0;
+            for (int c = 0; c < s_.n_cams; ++c) {
+                cam_var_[c] = o.optimize_extrinsics ? 1 : 0;
+                for (int k = 0; k < 6; ++k) active_[6 + c * s_.PC + k] = cam_var_[c];
+                mask_intr(6 + c * s_.PC + 6);
+            }
+        }
+        // bounds fx, fy >= 0 exist on every variable intrinsics block (intrinsics.cpp:81-82,
+        // extrinsics.cpp:142-144, bundle.cpp:118-123) => Ceres treats the problem as constrained
+        constrained_ = intr_var_;
+        view_fixed_ = fixed;
+        be_.set_view_fixed(fixed);
+    }
+
+    void solve(const cba_options& o, cba_summary* out) {
+        const auto t0 = std::chrono::steady_clock::now();
+        setup(o);
+        const int n = s_.nsh;
+        const double eps = o.epsilon, huber = o.huber_delta;
+        const double min_radius = 1e-32, max_radius = 1e16, min_rel_decrease = 1e-3;
+        double radius = 1e4, decrease_factor = 2.0;
+        int iter = 0, invalid = 0, successful = 0;
+
+        project_shared();  // Ceres projects the start point onto the bounds
+        be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
+        new_system(radius, true, huber);
+        const double initial_cost = cost_;
+        int term = CBA_TERM_FAILURE;
+        const char* msg = "";
+        std::vector<double> delta(n, 0.0), tintr, tcam, ttarget;
+
+        auto done = [&](int t, const char* m) { term = t; msg = m; };
+        if (gmax_ <= eps) {
+            done(CBA_TERM_CONVERGENCE, "Gradient tolerance reached.");
+        } else {
+            while (true) {
+                if (iter >= o.max_iterations) { done(CBA_TERM_NO_CONVERGENCE, "Maximum number of iterations reached."); break; }
+                if (gmax_ <= eps) { done(CBA_TERM_CONVERGENCE, "Gradient tolerance reached."); break; }
+                if (radius <= min_radius) { done(CBA_TERM_CONVERGENCE, "Minimum trust region radius reached."); break; }
+                ++iter;
+                bool valid = solve_reduced(radius, delta);
+                TrialStats st;
+                double step2_sh = 0, xnorm2_sh = 0, model_change = 0;
+                if (valid) {
+                    shared_plus(delta, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
+                    be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
+                    be_.trial(delta.data(), huber, &st);
+                    double buf[5] = {st.gd, st.dHd, st.step2, st.xnorm2, st.cost};
+                    ar_(buf, 5);
+                    st.gd = buf[0]; st.dHd = buf[1]; st.step2 = buf[2]; st.xnorm2 = buf[3]; st.cost = buf[4];
+                    // model_cost_change = -(J d)^T (r + J d / 2)  (trust_region_minimizer.cc)
+                    model_change = -st.gd - 0.5 * st.dHd;
+                    if (!(model_change > 0.0) || !std::isfinite(model_change)) valid = false;
+                }
+                if (!valid) {
+                    if (++invalid >= 5) { done(CBA_TERM_FAILURE, "Number of consecutive invalid steps more than max."); break; }
+                    radius *= 0.5;
+                    resolve(radius);
+                    continue;
+                }
+                invalid = 0;
+                double cand_cost = st.cost;
+                if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+                const double step_norm = std::sqrt(st.step2 + step2_sh);
+                const double x_norm = std::sqrt(st.xnorm2 + xnorm2_sh);
+                if (step_norm <= eps * (x_norm + eps)) { done(CBA_TERM_CONVERGENCE, "Parameter tolerance reached."); break; }
+                const double cost_change = cost_ - cand_cost;
+                if (std::fabs(cost_change) <= eps * cost_) { done(CBA_TERM_CONVERGENCE, "Function tolerance reached."); break; }
+                const double rel = cost_change / model_change;
+                if (o.verbose)
+                    std::printf("[cba] it %3d cost %.12e cand %.12e rel %.3e radius %.3e |g| %.3e\n", iter, cost_, cand_cost,
+                                rel, radius, gmax_);
+                if (rel > min_rel_decrease) {
+                    intr_ = tintr; cam_ = tcam; target_ = ttarget;
+                    be_.accept();
+                    be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
+                    ++successful;
+                    radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+                    radius = std::min(max_radius, radius);
+                    decrease_factor = 2.0;
+                    new_system(radius, false, huber);
+                } else {
+                    radius = radius / decrease_factor;
+                    decrease_factor *= 2.0;
+                    resolve(radius);
+                }
+            }
+        }
+        if (!view_.empty()) be_.download_private(view_.data());
+        out->termination = term;
+        out->success = term == CBA_TERM_CONVERGENCE;
+        out->iterations = iter;
+        out->successful_steps = successful;
+        out->initial_cost = initial_cost;
+        out->final_cost = cost_;
+        out->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::snprintf(out->report, sizeof(out->report), "calibba(schur LM, %d rank%s): %s iters=%d cost %.6e -> %.6e", n_ranks_,
+                      n_ranks_ > 1 ? "s" : "", msg, iter, initial_cost, cost_);
+    }
+
+    // ---- covariance in the reference's layout (ceresutils.h:69-126) ----------------------------
+    int64_t covariance_dim() const {
+        int64_t n = static_cast<int64_t>(s_.n_cams) * s_.PI;
+        if (s_.chain != CBA_CHAIN_INTRINSIC) n += 7LL * s_.n_cams;
+        if (s_.chain != CBA_CHAIN_BUNDLE) n += 7LL * s_.n_views;
+        else n += 7;
+        return n;
+    }
+
+    void covariance(const cba_options& o, double* cov) {
+        setup(o);
+        const int n = s_.nsh, PL = s_.PL, NH = s_.NH, NACC = s_.NACC;
+        if (covariance_dim() > 20000) throw std::runtime_error("covariance: dense ambient matrix too large (use compute_covariance=false)");
+        be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
+        std::vector<double> cam_acc, acc, w;
+        double cost2[2];
+        be_.normal_eq(o.huber_delta, cam_acc, cost2);
+        be_.download_blocks(acc, w);
+        if (!view_.empty()) be_.download_private(view_.data());
+        // shared Hessian over ALL ranks
+        std::vector<double> Hcc(static_cast<size_t>(n) * n, 0.0), gc(n, 0.0);
+        {
+            std::vector<double> buf = cam_acc;
+            ar_(buf.data(), static_cast<int64_t>(buf.size()));
+            assemble_shared(buf, Hcc, gc);
+        }
+        // compact active shared indices
+        std::vector<int> act;
+        for (int i = 0; i < n; ++i)
+            if (active_[i] && Hcc[static_cast<size_t>(i) * n + i] != 0.0) act.push_back(i);
+        const int na = static_cast<int>(act.size());
+        std::vector<int> free_views;
+        for (int v = 0; v < s_.n_views; ++v)
+            if (!view_fixed_[v]) free_views.push_back(v);
+        const int nv = static_cast<int>(free_views.size());
+        // per view: Hpp^-1 (6x6) and W_v = Hpp^-1 E_v (6 x na)
+        std::vector<double> Hinv(static_cast<size_t>(nv) * 36), W(static_cast<size_t>(nv) * 6 * std::max(na, 1), 0.0);
+        std::vector<double> S0(static_cast<size_t>(na) * na, 0.0);
+        for (int a = 0; a < na; ++a)
+            for (int b = 0; b < na; ++b) S0[static_cast<size_t>(a) * na + b] = Hcc[static_cast<size_t>(act[a]) * n + act[b]];
+        std::vector<int> pos(n, -1);
+        for (int a = 0; a < na; ++a) pos[act[a]] = a;
+        std::vector<double> Sloc(static_cast<size_t>(na) * na, 0.0);
+        for (int fv = 0; fv < nv; ++fv) {
+            const int v = free_views[fv];
+            std::vector<double> H(36, 0.0), E(static_cast<size_t>(6) * std::max(na, 1), 0.0);
+            for (int64_t k = s_.link_off[v]; k < s_.link_off[v + 1]; ++k) {
+                const int b = s_.link_blk[k];
+                const double* A = &acc[static_cast<size_t>(b) * NACC];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) H[i * 6 + j] += w[b] * A[hidx_sym(PL, i, j)];
+                for (int lc = 6; lc < PL; ++lc) {
+                    const int g = s_.shared_col(s_.blk_cam[b], lc);
+                    if (pos[g] < 0) continue;
+                    for (int i = 0; i < 6; ++i) E[static_cast<size_t>(i) * na + pos[g]] += w[b] * A[hidx(PL, i, lc)];
+                }
+            }
+            std::vector<double> L = H;
+            if (!chol_inplace(L, 6)) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
+            std::vector<double> Hi;
+            chol_inverse(L, 6, Hi);
+            std::memcpy(&Hinv[static_cast<size_t>(fv) * 36], Hi.data(), sizeof(double) * 36);
+            double* Wv = &W[static_cast<size_t>(fv) * 6 * std::max(na, 1)];
+            for (int i = 0; i < 6; ++i)
+                for (int a = 0; a < na; ++a) {
+                    double sum = 0;
+                    for (int k = 0; k < 6; ++k) sum += Hi[i * 6 + k] * E[static_cast<size_t>(k) * na + a];
+                    Wv[static_cast<size_t>(i) * na + a] = sum;
+                }
+            for (int a = 0; a < na; ++a)
+                for (int b = 0; b < na; ++b) {
+                    double sum = 0;
+                    for (int k = 0; k < 6; ++k) sum += E[static_cast<size_t>(k) * na + a] * Wv[static_cast<size_t>(k) * na + b];
+                    Sloc[static_cast<size_t>(a) * na + b] += sum;
+                }
+        }
+        if (na > 0) ar_(Sloc.data(), static_cast<int64_t>(Sloc.size()));
+        for (size_t i = 0; i < S0.size(); ++i) S0[i] -= Sloc[i];
+        std::vector<double> Lc = S0, Scc;
+        if (na > 0) {
+            if (!chol_inplace(Lc, na)) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
+            double dmin = 1e300, dmax = 0;
+            for (int i = 0; i < na; ++i) { dmin = std::min(dmin, Lc[static_cast<size_t>(i) * na + i]); dmax = std::max(dmax, Lc[static_cast<size_t>(i) * na + i]); }
+            if ((dmin / dmax) * (dmin / dmax) < 1e-14) throw std::runtime_error("covariance: rank deficient Jacobian (condition number)");
+            chol_inverse(Lc, na, Scc);
+        }
+        // tangent covariance: [shared active (na) | free views (6 each)]
+        const int nt = na + 6 * nv;
+        std::vector<double> T(static_cast<size_t>(nt) * nt, 0.0);
+        for (int a = 0; a < na; ++a)
+            for (int b = 0; b < na; ++b) T[static_cast<size_t>(a) * nt + b] = Scc[static_cast<size_t>(a) * na + b];
+        std::vector<double> WS(static_cast<size_t>(nv) * 6 * std::max(na, 1), 0.0);  // W_v Scc
+        for (int fv = 0; fv < nv; ++fv)
+            for (int i = 0; i < 6; ++i)
+                for (int b = 0; b < na; ++b) {
+                    double sum = 0;
+                    const double* Wv = &W[static_cast<size_t>(fv) * 6 * na];
+                    for (int a = 0; a < na; ++a) sum += Wv[static_cast<size_t>(i) * na + a] * Scc[static_cast<size_t>(a) * na + b];
+                    WS[(static_cast<size_t>(fv) * 6 + i) * na + b] = sum;
+                    T[static_cast<size_t>(na + 6 * fv + i) * nt + b] = -sum;
+                    T[static_cast<size_t>(b) * nt + na + 6 * fv + i] = -sum;
+                }
+        for (int fv = 0; fv < nv; ++fv)
+            for (int fw = 0; fw < nv; ++fw)
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double sum = fv == fw ? Hinv[static_cast<size_t>(fv) * 36 + i * 6 + j] : 0.0;
+                        const double* Ww = &W[static_cast<size_t>(fw) * 6 * std::max(na, 1)];
+                        for (int a = 0; a < na; ++a) sum += WS[(static_cast<size_t>(fv) * 6 + i) * na + a] * Ww[static_cast<size_t>(j) * na + a];
+                        T[static_cast<size_t>(na + 6 * fv + i) * nt + na + 6 * fw + j] = sum;
+                    }
+        // ambient rows: each is a short linear combination of tangent coordinates
+        struct Row { int t[3]; double c[3]; int n; };
+        std::vector<Row> rows;
+        auto push_zero = [&](int count) { for (int i = 0; i < count; ++i) rows.push_back(Row{{0, 0, 0}, {0, 0, 0}, 0}); };
+        auto push_euclid = [&](int tbase_global, int count) {  // shared euclidean columns
+            for (int k = 0; k < count; ++k) {
+                const int p = pos[tbase_global + k];
+                if (p < 0) push_zero(1);
+                else rows.push_back(Row{{p, 0, 0}, {1.0, 0, 0}, 1});
+            }
+        };
+        auto push_quat = [&](const double* q, const int* t3) {  // PlusJacobian rows (4x3)
+            const double PJ[12] = {-q[1], -q[2], -q[3], q[0], q[3], -q[2], -q[3], q[0], q[1], q[2], -q[1], q[0]};
+            for (int r = 0; r < 4; ++r) {
+                Row row{{0, 0, 0}, {0, 0, 0}, 0};
+                for (int k = 0; k < 3; ++k)
+                    if (t3[k] >= 0) { row.t[row.n] = t3[k]; row.c[row.n] = PJ[r * 3 + k]; ++row.n; }
+                rows.push_back(row);
+            }
+        };
+        auto sh3 = [&](int gbase, int* t3) { for (int k = 0; k < 3; ++k) t3[k] = pos[gbase + k]; };
+        int t3[3];
+        // block order of get_param_blocks(): intrinsics.cpp:34-50, extrinsics.cpp:50-67, bundle.cpp:48-68
+        for (int c = 0; c < s_.n_cams; ++c) push_euclid(intr_base(c), s_.PI);
+        if (s_.chain != CBA_CHAIN_INTRINSIC) {
+            for (int c = 0; c < s_.n_cams; ++c) { sh3(campose_base(c), t3); push_quat(&cam_[7 * static_cast<size_t>(c)], t3); }
+            for (int c = 0; c < s_.n_cams; ++c) push_euclid(campose_base(c) + 3, 3);
+        }
+        if (s_.chain != CBA_CHAIN_BUNDLE) {
+            std::vector<int> fidx(s_.n_views, -1);
+            for (int fv = 0; fv < nv; ++fv) fidx[free_views[fv]] = fv;
+            for (int v = 0; v < s_.n_views; ++v) {
+                if (fidx[v] < 0) { push_zero(4); continue; }
+                for (int k = 0; k < 3; ++k) t3[k] = na + 6 * fidx[v] + k;
+                push_quat(&view_[7 * static_cast<size_t>(v)], t3);
+            }
+            for (int v = 0; v < s_.n_views; ++v) {
+                if (fidx[v] < 0) { push_zero(3); continue; }
+                for (int k = 0; k < 3; ++k) rows.push_back(Row{{na + 6 * fidx[v] + 3 + k, 0, 0}, {1.0, 0, 0}, 1});
+            }
+        } else {
+            sh3(0, t3); push_quat(target_.data(), t3);
+            push_euclid(3, 3);
+        }
+        const int64_t dim = static_cast<int64_t>(rows.size());
+        for (int64_t i = 0; i < dim; ++i)
+            for (int64_t j = 0; j < dim; ++j) {
+                double sum = 0;
+                for (int a = 0; a < rows[i].n; ++a)
+                    for (int b = 0; b < rows[j].n; ++b)
+                        sum += rows[i].c[a] * rows[j].c[b] * T[static_cast<size_t>(rows[i].t[a]) * nt + rows[j].t[b]];
+                cov[i * dim + j] = sum;
+            }
+        (void)NH;
+    }
+
+  private:
+    int intr_base(int c) const { return s_.chain == CBA_CHAIN_INTRINSIC ? 0 : s_.sh_base + c * s_.PC + 6; }
+    int campose_base(int c) const { return s_.sh_base + c * s_.PC; }
+
+    void project_shared() {
+        if (!intr_var_) return;
+        for (int c = 0; c < s_.n_cams; ++c) {
+            double* p = &intr_[static_cast<size_t>(c) * s_.PI];
+            p[0] = std::max(p[0], 0.0);
+            p[1] = std::max(p[1], 0.0);
+        }
+    }
+
+    // H_cc / g_c from the (all-reduced) weighted per-camera local sums
+    void assemble_shared(const std::vector<double>& cam_acc, std::vector<double>& Hcc, std::vector<double>& gc) const {
+        const int n = s_.nsh, PL = s_.PL;
+        std::fill(Hcc.begin(), Hcc.end(), 0.0);
+        std::fill(gc.begin(), gc.end(), 0.0);
+        for (int c = 0; c < s_.n_cams; ++c) {
+            const double* A = &cam_acc[static_cast<size_t>(c) * s_.NACC];
+            for (int i = 0; i < PL; ++i) {
+                const int gi = s_.shared_col(c, i);
+                if (gi < 0) continue;
+                gc[gi] += A[s_.NH + i];
+                for (int j = 0; j < PL; ++j) {
+                    const int gj = s_.shared_col(c, j);
+                    if (gj < 0) continue;
+                    Hcc[static_cast<size_t>(gi) * n + gj] += A[hidx_sym(PL, i, j)];
+                }
+            }
+        }
+    }
+
+    // Evaluate J at the current point and eliminate with `radius`: one packed all-reduce.
+    void new_system(double radius, bool init_scale, double huber) {
+        const int n = s_.nsh;
+        std::vector<double> cam_acc, S, g;
+        double cost2[2] = {0, 0}, gmax_priv = 0;
+        int nfail = 0;
+        be_.normal_eq(huber, cam_acc, cost2);
+        be_.schur(radius, init_scale, constrained_, S, g, &gmax_priv, &nfail);
+        const size_t nca = cam_acc.size();
+        std::vector<double> buf(nca + 2 + static_cast<size_t>(n) * n + n + n_ranks_, 0.0);
+        std::memcpy(buf.data(), cam_acc.data(), sizeof(double) * nca);
+        buf[nca] = cost2[0];
+        buf[nca + 1] = nfail;
+        std::memcpy(&buf[nca + 2], S.data(), sizeof(double) * S.size());
+        std::memcpy(&buf[nca + 2 + static_cast<size_t>(n) * n], g.data(), sizeof(double) * n);
+        buf[nca + 2 + static_cast<size_t>(n) * n + n + rank_] = gmax_priv;  // max over ranks via per-rank slots
+        ar_(buf.data(), static_cast<int64_t>(buf.size()));
+        cam_acc.assign(buf.begin(), buf.begin() + nca);
+        cost_ = buf[nca];
+        nfail_ = static_cast<int>(buf[nca + 1] + 0.5);
+        Ssch_.assign(buf.begin() + nca + 2, buf.begin() + nca + 2 + static_cast<size_t>(n) * n);
+        gsch_.assign(buf.begin() + nca + 2 + static_cast<size_t>(n) * n, buf.begin() + nca + 2 + static_cast<size_t>(n) * n + n);
+        double gm = 0;
+        for (int r = 0; r < n_ranks_; ++r) gm = std::max(gm, buf[nca + 2 + static_cast<size_t>(n) * n + n + r]);
+        Hcc_.assign(static_cast<size_t>(n) * n, 0.0);
+        gc_.assign(n, 0.0);
+        assemble_shared(cam_acc, Hcc_, gc_);
+        // columns nobody observes (H_ii == 0) behave like constant blocks
+        eff_.assign(n, 0);
+        for (int i = 0; i < n; ++i) eff_[i] = active_[i] && Hcc_[static_cast<size_t>(i) * n + i] != 0.0;
+        if (init_scale) {
+            scale2_.assign(n, 1.0);
+            for (int i = 0; i < n; ++i) {
+                const double sc = 1.0 / (1.0 + std::sqrt(Hcc_[static_cast<size_t>(i) * n + i]));
+                scale2_[i] = sc * sc;
+            }
+        }
+        gmax_ = std::max(gm, shared_gmax());
+    }
+
+    void resolve(double radius) {
+        const int n = s_.nsh;
+        std::vector<double> S, g;
+        double gmax_priv = 0;
+        int nfail = 0;
+        be_.schur(radius, false, constrained_, S, g, &gmax_priv, &nfail);
+        std::vector<double> buf(1 + static_cast<size_t>(n) * n + n, 0.0);
+        buf[0] = nfail;
+        std::memcpy(&buf[1], S.data(), sizeof(double) * S.size());
+        std::memcpy(&buf[1 + static_cast<size_t>(n) * n], g.data(), sizeof(double) * n);
+        ar_(buf.data(), static_cast<int64_t>(buf.size()));
+        nfail_ = static_cast<int>(buf[0] + 0.5);
+        Ssch_.assign(buf.begin() + 1, buf.begin() + 1 + static_cast<size_t>(n) * n);
+        gsch_.assign(buf.begin() + 1 + static_cast<size_t>(n) * n, buf.end());
+    }
+
+    double shared_gmax() const {
+        const int n = s_.nsh;
+        double m = 0;
+        if (!constrained_) {
+            for (int i = 0; i < n; ++i)
+                if (eff_[i]) m = std::max(m, std::fabs(gc_[i]));
+            return m;
+        }
+        // |Plus(x, -g) - x|_inf over the shared blocks
+        std::vector<double> ng(n, 0.0), ti, tc, tt;
+        for (int i = 0; i < n; ++i)
+            if (eff_[i]) ng[i] = -gc_[i];
+        double s2, x2;
+        shared_plus(ng, ti, tc, tt, &s2, &x2);
+        for (size_t i = 0; i < ti.size(); ++i) m = std::max(m, std::fabs(ti[i] - intr_[i]));
+        for (size_t i = 0; i < tc.size(); ++i) m = std::max(m, std::fabs(tc[i] - cam_[i]));
+        for (size_t i = 0; i < tt.size(); ++i) m = std::max(m, std::fabs(tt[i] - target_[i]));
+        return m;
+    }
+
+    // (H_cc + D_c - S_schur) delta_c = -(g_c - g_schur) on the effective columns
+    bool solve_reduced(double radius, std::vector<double>& delta) {
+        const int n = s_.nsh;
+        if (nfail_ > 0) return false;
+        std::vector<int> idx;
+        for (int i = 0; i < n; ++i)
+            if (eff_[i]) idx.push_back(i);
+        const int m = static_cast<int>(idx.size());
+        std::fill(delta.begin(), delta.end(), 0.0);
+        if (m == 0) return true;
+        std::vector<double> A(static_cast<size_t>(m) * m), b(m);
+        for (int a = 0; a < m; ++a) {
+            const int i = idx[a];
+            for (int c = 0; c < m; ++c) {
+                const int j = idx[c];
+                A[static_cast<size_t>(a) * m + c] = Hcc_[static_cast<size_t>(i) * n + j] - Ssch_[static_cast<size_t>(i) * n + j];
+            }
+            A[static_cast<size_t>(a) * m + a] += lm_diag_host(Hcc_[static_cast<size_t>(i) * n + i], scale2_[i], radius);
+            b[a] = -(gc_[i] - gsch_[i]);
+        }
+        if (!chol_inplace(A, m)) return false;
+        chol_solve(A, m, b.data());
+        for (int a = 0; a < m; ++a) {
+            if (!std::isfinite(b[a])) return false;
+            delta[idx[a]] = b[a];
+        }
+        return true;
+    }
+
+    static double lm_diag_host(double hii, double scale2, double radius) {
+        double ds = hii * scale2;
+        ds = std::min(std::max(ds, 1e-6), 1e32);
+        return ds / radius / scale2;
+    }
+
+    // Plus on the shared blocks (+ bounds projection); also the shared share of |x+ - x|^2, |x|^2
+    void shared_plus(const std::vector<double>& delta, std::vector<double>& ti, std::vector<double>& tc,
+                     std::vector<double>& tt, double* step2, double* xnorm2) const {
+        ti = intr_; tc = cam_; tt = target_;
+        double s2 = 0, x2 = 0;
+        for (int c = 0; c < s_.n_cams; ++c) {
+            const int ib = intr_base(c);
+            double* p = &ti[static_cast<size_t>(c) * s_.PI];
+            if (intr_var_) {
+                for (int k = 0; k < s_.PI; ++k) p[k] += delta[ib + k];
+                p[0] = std::max(p[0], 0.0);
+                p[1] = std::max(p[1], 0.0);
+                for (int k = 0; k < s_.PI; ++k) {
+                    const double o = intr_[static_cast<size_t>(c) * s_.PI + k];
+                    s2 += (p[k] - o) * (p[k] - o);
+                    x2 += o * o;
+                }
+            }
+            if (s_.chain != CBA_CHAIN_INTRINSIC && cam_var_[c]) {
+                const int pb = campose_base(c);
+                const double* q = &cam_[7 * static_cast<size_t>(c)];
+                double* o = &tc[7 * static_cast<size_t>(c)];
+                quat_plus(q, &delta[pb], o);
+                for (int k = 0; k < 3; ++k) o[4 + k] = q[4 + k] + delta[pb + 3 + k];
+                for (int k = 0; k < 7; ++k) { s2 += (o[k] - q[k]) * (o[k] - q[k]); x2 += q[k] * q[k]; }
+            }
+        }
+        if (s_.chain == CBA_CHAIN_BUNDLE && target_var_) {
+            quat_plus(target_.data(), &delta[0], tt.data());
+            for (int k = 0; k < 3; ++k) tt[4 + k] = target_[4 + k] + delta[3 + k];
+            for (int k = 0; k < 7; ++k) { s2 += (tt[k] - target_[k]) * (tt[k] - target_[k]); x2 += target_[k] * target_[k]; }
+        }
+        *step2 = s2;
+        *xnorm2 = x2;
+    }
+
+    const Structure& s_;
+    Backend& be_;
+    std::vector<double>&intr_, &cam_, &view_, &target_;
+    AllReduce ar_;
+    int n_ranks_, rank_;
+    std::vector<char> active_, eff_;
+    std::vector<char> cam_var_;
+    std::vector<int32_t> view_fixed_;
+    bool intr_var_ = true, target_var_ = false, constrained_ = true;
+    std::vector<double> Hcc_, gc_, Ssch_, gsch_, scale2_;
+    double cost_ = 0, gmax_ = 0;
+    int nfail_ = 0;
+};
+
+}  // namespace cba

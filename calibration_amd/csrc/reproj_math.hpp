@@ -1,0 +1,296 @@
+// reproj_math.hpp — per-observation reprojection residual + ANALYTIC tangent-space Jacobian.
+//
+// This is the arithmetic of the hot path, written once as __host__ __device__ inline code.  The
+// HIP kernels (kernels_reproj.hip) call it per lane; tests/cpu_backend compiles the very same
+// header with g++ to check the analytic derivatives against the oracle's dual numbers without a
+// GPU.  It is NOT a CPU fallback: the product library only instantiates it in device code.
+//
+// What it replaces in the reference (evaluated there through ceres::Jet autodiff):
+//   rigid chains     src/estimation/residuals/intrinsicresidual.h:20-35,
+//                    extrinsicsresidual.h:14-46, bundleresidual.h:15-56
+//   pose helpers     src/estimation/detail/observationutils.h:20-41
+//   pinhole + BC     include/calib/models/pinhole.h:102-107, distortion.h:91-116,
+//                    camera_matrix.h:41-46
+//   Scheimpflug      include/calib/models/scheimpflug.h:139-181
+//   manifold         ceres::QuaternionManifold: x+ = q(delta) (x) x, i.e. R+ = exp([2 delta]x) R
+//
+// Local tangent column order of one observation (cba_local_columns()):
+//   [ poseA: d(3) t(3) | poseB: d(3) t(3) (EXTRINSIC/BUNDLE only) | intrinsics (10 | 12) ]
+//   INTRINSIC: A = c_T_t                      EXTRINSIC: A = r_T_t, B = c_T_r
+//   BUNDLE:    A = b_T_t, B = g_T_c
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define CBA_HD __host__ __device__ __forceinline__
+#else
+#define CBA_HD inline
+#endif
+
+namespace cba {
+
+enum { CH_INTRINSIC = 0, CH_EXTRINSIC = 1, CH_BUNDLE = 2 };
+enum { CAM_PINHOLE_BC = 0, CAM_SCHEIMPFLUG = 1 };
+
+template <int MODEL> struct IntrSize { static constexpr int value = MODEL == CAM_SCHEIMPFLUG ? 12 : 10; };
+template <int CHAIN, int MODEL> struct LocalCols {
+    static constexpr int value = (CHAIN == CH_INTRINSIC ? 6 : 12) + IntrSize<MODEL>::value;
+};
+
+// ---- per-block constants (computed once per residual block by k_block_consts) -----------------
+// P = X*m1 + Y*m2 + p0 is the camera-frame point of target point (X, Y, 0).
+//   a1, a2 : columns 0,1 of R_A (rotation of pose A)         c = X a1 + Y a2 = R_A (X,Y,0)
+//   M      : dP/d(t_A)                                        (I | R_cr | R_gc^T R_bg^T)
+//   N, tb  : pose-B helpers (EXTRINSIC: tb = t_cr; BUNDLE: N = R_gc^T)
+constexpr int BC_M1 = 0, BC_M2 = 3, BC_P0 = 6, BC_A1 = 9, BC_A2 = 12, BC_M = 15, BC_N = 24, BC_TB = 33, BC_SIZE = 36;
+
+CBA_HD void quat_to_rotmat(const double* q, double* R) {
+    // Eigen::Quaternion::toRotationMatrix, no normalisation (observationutils.h:20-24)
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+CBA_HD void mat3_mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+CBA_HD void mat3_vec(const double* A, const double* x, double* y) {
+    for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+CBA_HD void mat3_tvec(const double* A, const double* x, double* y) {  // y = A^T x
+    for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+
+// poseA / poseB: 7-vectors [qw qx qy qz tx ty tz]; bTg: rotation row-major(9) + translation(3)
+template <int CHAIN>
+CBA_HD void block_consts(const double* poseA, const double* poseB, const double* bTg, double* bc) {
+    double RA[9];
+    quat_to_rotmat(poseA, RA);
+    const double* tA = poseA + 4;
+    for (int i = 0; i < 3; ++i) { bc[BC_A1 + i] = RA[3 * i]; bc[BC_A2 + i] = RA[3 * i + 1]; }
+    for (int i = 0; i < 9; ++i) bc[BC_N + i] = 0.0;
+    for (int i = 0; i < 3; ++i) bc[BC_TB + i] = 0.0;
+    if (CHAIN == CH_INTRINSIC) {
+        for (int i = 0; i < 9; ++i) bc[BC_M + i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) { bc[BC_M1 + i] = RA[3 * i]; bc[BC_M2 + i] = RA[3 * i + 1]; bc[BC_P0 + i] = tA[i]; }
+    } else if (CHAIN == CH_EXTRINSIC) {
+        // c_T_t = c_T_r * r_T_t (extrinsicsresidual.h:14-20, product(): observationutils.h:34-41)
+        double RB[9], R[9], t[3];
+        quat_to_rotmat(poseB, RB);
+        mat3_mul(RB, RA, R);
+        mat3_vec(RB, tA, t);
+        for (int i = 0; i < 9; ++i) bc[BC_M + i] = RB[i];
+        for (int i = 0; i < 3; ++i) {
+            bc[BC_M1 + i] = R[3 * i]; bc[BC_M2 + i] = R[3 * i + 1];
+            bc[BC_P0 + i] = t[i] + poseB[4 + i];
+            bc[BC_TB + i] = poseB[4 + i];
+        }
+    } else {
+        // c_T_t = (g_T_c)^-1 * (b_T_g)^-1 * b_T_t (bundleresidual.h:15-27)
+        double RB[9], Rcg[9], tcg[3], Rgb[9], tgb[3], Rcb[9], tcb[3], R[9], t[3], tmp[3];
+        quat_to_rotmat(poseB, RB);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Rcg[3 * i + j] = RB[3 * j + i]; Rgb[3 * i + j] = bTg[3 * j + i]; }
+        mat3_vec(Rcg, poseB + 4, tmp); for (int i = 0; i < 3; ++i) tcg[i] = -tmp[i];
+        mat3_vec(Rgb, bTg + 9, tmp);   for (int i = 0; i < 3; ++i) tgb[i] = -tmp[i];
+        mat3_mul(Rcg, Rgb, Rcb);
+        mat3_vec(Rcg, tgb, tmp);       for (int i = 0; i < 3; ++i) tcb[i] = tmp[i] + tcg[i];
+        mat3_mul(Rcb, RA, R);
+        mat3_vec(Rcb, tA, tmp);        for (int i = 0; i < 3; ++i) t[i] = tmp[i] + tcb[i];
+        for (int i = 0; i < 9; ++i) { bc[BC_M + i] = Rcb[i]; bc[BC_N + i] = Rcg[i]; }
+        for (int i = 0; i < 3; ++i) { bc[BC_M1 + i] = R[3 * i]; bc[BC_M2 + i] = R[3 * i + 1]; bc[BC_P0 + i] = t[i]; }
+    }
+}
+
+// ---- per-camera derived constants for the Scheimpflug model ------------------------------------
+// Rs (9) | dRs/dtau_x (9) | dRs/dtau_y (9) | m0 (2) | dm0/dtau_x (2) | dm0/dtau_y (2)
+constexpr int SD_RS = 0, SD_DX = 9, SD_DY = 18, SD_M0 = 27, SD_DM0X = 29, SD_DM0Y = 31, SD_SIZE = 36;
+
+CBA_HD void scheimpflug_consts(const double* intr, double* sd) {
+    const double ctx = cos(intr[10]), stx = sin(intr[10]), cty = cos(intr[11]), sty = sin(intr[11]);
+    // rot_sensor rows, scheimpflug.h:150-152
+    const double Rs[9] = {cty, stx * sty, ctx * sty, 0.0, ctx, -stx, -sty, stx * cty, ctx * cty};
+    const double Dx[9] = {0.0, ctx * sty, -stx * sty, 0.0, -stx, -ctx, 0.0, ctx * cty, -stx * cty};
+    const double Dy[9] = {-sty, stx * cty, ctx * cty, 0.0, 0.0, 0.0, -cty, -stx * sty, -ctx * sty};
+    for (int i = 0; i < 9; ++i) { sd[SD_RS + i] = Rs[i]; sd[SD_DX + i] = Dx[i]; sd[SD_DY + i] = Dy[i]; }
+    const double s0 = Rs[8];
+    const double mx0 = Rs[6] / s0, my0 = Rs[7] / s0;  // scheimpflug.h:165-167
+    sd[SD_M0] = mx0; sd[SD_M0 + 1] = my0;
+    sd[SD_DM0X] = (Dx[6] - mx0 * Dx[8]) / s0; sd[SD_DM0X + 1] = (Dx[7] - my0 * Dx[8]) / s0;
+    sd[SD_DM0Y] = (Dy[6] - mx0 * Dy[8]) / s0; sd[SD_DM0Y + 1] = (Dy[7] - my0 * Dy[8]) / s0;
+}
+
+CBA_HD void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Residual only.  bc: block constants, intr: camera params, sd: Scheimpflug constants (unused for
+// pinhole).  Returns r = (u - u_obs, v - v_obs).
+template <int MODEL>
+CBA_HD void reproj_residual(const double* bc, const double* intr, const double* sd, double X, double Y, double uo,
+                            double vo, double* r) {
+    const double P0 = X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0];
+    const double P1 = X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1];
+    const double P2 = X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2];
+    double x, y, su = 0.0, sv = 0.0;
+    if (MODEL == CAM_PINHOLE_BC) {
+        const double iz = 1.0 / P2;
+        x = P0 * iz; y = P1 * iz;
+    } else {
+        const double* Rs = sd + SD_RS;
+        const double is = 1.0 / (Rs[2] * P0 + Rs[5] * P1 + Rs[8] * P2);
+        x = (Rs[0] * P0 + Rs[3] * P1 + Rs[6] * P2) * is - sd[SD_M0];
+        y = (Rs[1] * P0 + Rs[4] * P1 + Rs[7] * P2) * is - sd[SD_M0 + 1];
+        su = intr[0] * sd[SD_M0] + intr[4] * sd[SD_M0 + 1];
+        sv = intr[1] * sd[SD_M0 + 1];
+    }
+    const double r2 = x * x + y * y;
+    const double rad = 1.0 + r2 * (intr[5] + r2 * (intr[6] + r2 * intr[7]));
+    const double xy = x * y;
+    const double xd = x * rad + 2.0 * intr[8] * xy + intr[9] * (r2 + 2.0 * x * x);
+    const double yd = y * rad + intr[8] * (r2 + 2.0 * y * y) + 2.0 * intr[9] * xy;
+    r[0] = (intr[0] * xd + intr[4] * yd + intr[2] + su) - uo;
+    r[1] = (intr[1] * yd + intr[3] + sv) - vo;
+}
+
+// Residual + Jacobian rows.  Ju/Jv: LocalCols<CHAIN,MODEL>::value entries each.
+template <int CHAIN, int MODEL>
+CBA_HD void reproj_point(const double* bc, const double* intr, const double* sd, double X, double Y, double uo,
+                         double vo, double* r, double* Ju, double* Jv) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    constexpr int OI = CHAIN == CH_INTRINSIC ? 6 : 12;  // offset of the intrinsics columns
+    const double fx = intr[0], fy = intr[1], skew = intr[4];
+    const double k1 = intr[5], k2 = intr[6], k3 = intr[7], p1 = intr[8], p2 = intr[9];
+
+    const double P[3] = {X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0],
+                         X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1],
+                         X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2]};
+    // (x, y) = normalised coordinates fed to Brown-Conrady and d(x,y)/dP rows gx, gy
+    double x, y, gx[3], gy[3], m0x = 0.0, m0y = 0.0, mx = 0.0, my = 0.0, is = 0.0;
+    if (MODEL == CAM_PINHOLE_BC) {
+        const double iz = 1.0 / P[2];
+        x = P[0] * iz; y = P[1] * iz;
+        gx[0] = iz; gx[1] = 0.0; gx[2] = -x * iz;
+        gy[0] = 0.0; gy[1] = iz; gy[2] = -y * iz;
+    } else {
+        const double* Rs = sd + SD_RS;
+        is = 1.0 / (Rs[2] * P[0] + Rs[5] * P[1] + Rs[8] * P[2]);
+        mx = (Rs[0] * P[0] + Rs[3] * P[1] + Rs[6] * P[2]) * is;
+        my = (Rs[1] * P[0] + Rs[4] * P[1] + Rs[7] * P[2]) * is;
+        m0x = sd[SD_M0]; m0y = sd[SD_M0 + 1];
+        x = mx - m0x; y = my - m0y;
+        for (int i = 0; i < 3; ++i) {
+            gx[i] = (Rs[3 * i] - mx * Rs[3 * i + 2]) * is;
+            gy[i] = (Rs[3 * i + 1] - my * Rs[3 * i + 2]) * is;
+        }
+    }
+    const double r2 = x * x + y * y, xx = x * x, yy = y * y, xy = x * y;
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double drad = k1 + r2 * (2.0 * k2 + 3.0 * k3 * r2);
+    const double xd = x * rad + 2.0 * p1 * xy + p2 * (r2 + 2.0 * xx);
+    const double yd = y * rad + p1 * (r2 + 2.0 * yy) + 2.0 * p2 * xy;
+    r[0] = (fx * xd + skew * yd + intr[2] + (fx * m0x + skew * m0y)) - uo;
+    r[1] = (fy * yd + intr[3] + fy * m0y) - vo;
+
+    // d(xd,yd)/d(x,y)
+    const double dxdx = rad + 2.0 * xx * drad + 2.0 * p1 * y + 6.0 * p2 * x;
+    const double dxdy = 2.0 * xy * drad + 2.0 * p1 * x + 2.0 * p2 * y;  // = dyd/dx
+    const double dydy = rad + 2.0 * yy * drad + 6.0 * p1 * y + 2.0 * p2 * x;
+    // d(u,v)/d(x,y)
+    const double ux = fx * dxdx + skew * dxdy, uy = fx * dxdy + skew * dydy;
+    const double vx = fy * dxdy, vy = fy * dydy;
+    // d(u,v)/dP
+    double du[3], dv[3];
+    for (int i = 0; i < 3; ++i) { du[i] = ux * gx[i] + uy * gy[i]; dv[i] = vx * gx[i] + vy * gy[i]; }
+
+    // ---- pose A: dP/d(delta_A) = -2 M [c]x, dP/d(t_A) = M,  c = X a1 + Y a2 ----
+    const double c[3] = {X * bc[BC_A1] + Y * bc[BC_A2], X * bc[BC_A1 + 1] + Y * bc[BC_A2 + 1],
+                         X * bc[BC_A1 + 2] + Y * bc[BC_A2 + 2]};
+    double eu[3], ev[3], cr[3];
+    if (CHAIN == CH_INTRINSIC) {
+        for (int i = 0; i < 3; ++i) { eu[i] = du[i]; ev[i] = dv[i]; }
+    } else {
+        mat3_tvec(bc + BC_M, du, eu);  // row vector du^T M
+        mat3_tvec(bc + BC_M, dv, ev);
+    }
+    cross3(c, eu, cr); for (int i = 0; i < 3; ++i) { Ju[i] = 2.0 * cr[i]; Ju[3 + i] = eu[i]; }
+    cross3(c, ev, cr); for (int i = 0; i < 3; ++i) { Jv[i] = 2.0 * cr[i]; Jv[3 + i] = ev[i]; }
+
+    // ---- pose B ----
+    if (CHAIN == CH_EXTRINSIC) {
+        // dP/d(delta_B) = -2 [P - t_cr]x, dP/d(t_B) = I
+        const double w[3] = {P[0] - bc[BC_TB], P[1] - bc[BC_TB + 1], P[2] - bc[BC_TB + 2]};
+        cross3(w, du, cr); for (int i = 0; i < 3; ++i) { Ju[6 + i] = 2.0 * cr[i]; Ju[9 + i] = du[i]; }
+        cross3(w, dv, cr); for (int i = 0; i < 3; ++i) { Jv[6 + i] = 2.0 * cr[i]; Jv[9 + i] = dv[i]; }
+    } else if (CHAIN == CH_BUNDLE) {
+        // dP/d(delta_B) = 2 [P]x N, dP/d(t_B) = -N,  N = R_gc^T
+        double h[3], hn[3], dn[3];
+        cross3(du, P, h); mat3_tvec(bc + BC_N, h, hn); mat3_tvec(bc + BC_N, du, dn);
+        for (int i = 0; i < 3; ++i) { Ju[6 + i] = 2.0 * hn[i]; Ju[9 + i] = -dn[i]; }
+        cross3(dv, P, h); mat3_tvec(bc + BC_N, h, hn); mat3_tvec(bc + BC_N, dv, dn);
+        for (int i = 0; i < 3; ++i) { Jv[6 + i] = 2.0 * hn[i]; Jv[9 + i] = -dn[i]; }
+    }
+
+    // ---- intrinsics [fx fy cx cy skew k1 k2 k3 p1 p2 (tau_x tau_y)] ----
+    const double r4 = r2 * r2, r6 = r4 * r2;
+    const double t1x = 2.0 * xy, t1y = r2 + 2.0 * yy;  // d(xd,yd)/dp1
+    const double t2x = r2 + 2.0 * xx, t2y = 2.0 * xy;  // d(xd,yd)/dp2
+    Ju[OI + 0] = xd + m0x; Jv[OI + 0] = 0.0;
+    Ju[OI + 1] = 0.0;      Jv[OI + 1] = yd + m0y;
+    Ju[OI + 2] = 1.0;      Jv[OI + 2] = 0.0;
+    Ju[OI + 3] = 0.0;      Jv[OI + 3] = 1.0;
+    Ju[OI + 4] = yd + m0y; Jv[OI + 4] = 0.0;
+    const double gu = fx * x + skew * y, gv = fy * y;
+    Ju[OI + 5] = gu * r2;  Jv[OI + 5] = gv * r2;
+    Ju[OI + 6] = gu * r4;  Jv[OI + 6] = gv * r4;
+    Ju[OI + 7] = gu * r6;  Jv[OI + 7] = gv * r6;
+    Ju[OI + 8] = fx * t1x + skew * t1y; Jv[OI + 8] = fy * t1y;
+    Ju[OI + 9] = fx * t2x + skew * t2y; Jv[OI + 9] = fy * t2y;
+    if (MODEL == CAM_SCHEIMPFLUG) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double* D = sd + (k == 0 ? SD_DX : SD_DY);
+            const double* dm0 = sd + (k == 0 ? SD_DM0X : SD_DM0Y);
+            const double dnP = D[2] * P[0] + D[5] * P[1] + D[8] * P[2];
+            const double dmx = ((D[0] * P[0] + D[3] * P[1] + D[6] * P[2]) - mx * dnP) * is;
+            const double dmy = ((D[1] * P[0] + D[4] * P[1] + D[7] * P[2]) - my * dnP) * is;
+            const double dx = dmx - dm0[0], dy = dmy - dm0[1];
+            Ju[OI + 10 + k] = ux * dx + uy * dy + fx * dm0[0] + skew * dm0[1];
+            Jv[OI + 10 + k] = vx * dx + vy * dy + fy * dm0[1];
+        }
+    }
+    (void)PI;
+}
+
+// ---- Huber (ceres::HuberLoss + Corrector with rho'' <= 0): weight = rho'(s), rho(s) ------------
+CBA_HD void huber(double s, double delta, double* rho, double* w) {
+    if (delta > 0.0 && s > delta * delta) {
+        const double rt = sqrt(s);
+        *rho = 2.0 * delta * rt - delta * delta;
+        const double ww = delta / rt;
+        *w = ww > 2.2250738585072014e-308 ? ww : 2.2250738585072014e-308;
+    } else {
+        *rho = s;
+        *w = 1.0;
+    }
+}
+
+// ---- ceres::QuaternionManifold::Plus ----------------------------------------------------------
+CBA_HD void quat_plus(const double* q, const double* d, double* out) {
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n == 0.0) { for (int i = 0; i < 4; ++i) out[i] = q[i]; return; }
+    const double s = sin(n) / n;
+    const double a0 = cos(n), a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
+    out[0] = a0 * q[0] - a1 * q[1] - a2 * q[2] - a3 * q[3];
+    out[1] = a0 * q[1] + a1 * q[0] + a2 * q[3] - a3 * q[2];
+    out[2] = a0 * q[2] - a1 * q[3] + a2 * q[0] + a3 * q[1];
+    out[3] = a0 * q[3] + a1 * q[2] - a2 * q[1] + a3 * q[0];
+}
+
+}  // namespace cba

@@ -1,0 +1,189 @@
+// schur_math.hpp — per-view / per-block bodies of the Schur-complement step, as
+// __host__ __device__ inline code (the HIP kernels in backend_hip.hip are thin index wrappers;
+// tests/cpu_backend runs the same bodies on the host to check the LM logic without a GPU).
+//
+// Per private view v (pose A of the INTRINSIC / EXTRINSIC chains), with w_b = rho'(s_b) the Huber
+// weight of residual block b (ceres corrector with rho'' <= 0: J~ = sqrt(w) J, r~ = sqrt(w) r):
+//   H_pp = sum_b w_b H_b[A,A]        g_p = sum_b w_b g_b[A]        E_b = w_b H_b[A, shared cols]
+//   (H_pp + D_p) = L L^T             y = L^-1 g_p                  Z_b = L^-1 E_b
+// Reduced system contributions: S -= sum_v Z_v^T Z_v,  g_red -= sum_v Z_v^T y_v, and the
+// back-substitution  delta_p = -L^-T (y + Z_v delta_c).
+// D_p is the Levenberg-Marquardt diagonal in Ceres' convention with Jacobi scaling
+// (levenberg_marquardt_strategy.cc): D_ii = clamp(s_i^2 H_ii, 1e-6, 1e32) / (radius s_i^2),
+// s_i = 1 / (1 + sqrt(H_ii(x0))).
+#pragma once
+#include "reproj_math.hpp"
+
+namespace cba {
+
+struct SchurDims {
+    int PL, NH, NACC, PSH, PC, n_cams, chain;
+};
+
+CBA_HD int hidx(int PL, int i, int j) { return i * PL - i * (i - 1) / 2 + (j - i); }
+CBA_HD int hidx_sym(int PL, int i, int j) { return i <= j ? hidx(PL, i, j) : hidx(PL, j, i); }
+
+constexpr double LM_MIN_DIAG = 1e-6, LM_MAX_DIAG = 1e32;
+
+CBA_HD double lm_diag(double hii, double scale2, double radius) {
+    double ds = hii * scale2;
+    ds = ds < LM_MIN_DIAG ? LM_MIN_DIAG : (ds > LM_MAX_DIAG ? LM_MAX_DIAG : ds);
+    return ds / radius / scale2;
+}
+
+// in-place lower Cholesky of a 6x6 (row-major full storage); false if not positive definite
+CBA_HD bool chol6(double* A) {
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s / d;
+        }
+    }
+    return true;
+}
+CBA_HD void fwd6(const double* L, double* b) {  // b <- L^-1 b
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * b[k];
+        b[i] = s / L[i * 6 + i];
+    }
+}
+CBA_HD void bwd6(const double* L, double* b) {  // b <- L^-T b
+    for (int i = 5; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * b[k];
+        b[i] = s / L[i * 6 + i];
+    }
+}
+
+// Private-view elimination.  Outputs: L (36, lower), y (6), D (6), gp (6), scale2 (6, written when
+// init_scale), Z of every block of the view ([6][PSH] at blk_Z + b*6*PSH), *gmax = the view's
+// contribution to Ceres' gradient max-norm.  Returns false if the damped H_pp is not PD.
+CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, const double* blk_acc, const double* blk_w,
+                            bool fixed, double radius, bool init_scale, bool constrained, const double* xview7,
+                            double* scale2, double* L, double* y, double* D, double* gp, double* blk_Z, double* gmax) {
+    if (fixed) {
+        for (int i = 0; i < 36; ++i) L[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 6; ++i) { y[i] = 0.0; D[i] = 0.0; gp[i] = 0.0; if (init_scale) scale2[i] = 1.0; }
+        for (int k = 0; k < nb; ++k) {
+            double* Z = blk_Z + static_cast<long long>(blks[k]) * 6 * d.PSH;
+            for (int i = 0; i < 6 * d.PSH; ++i) Z[i] = 0.0;
+        }
+        *gmax = 0.0;
+        return true;
+    }
+    double H[36];
+    for (int i = 0; i < 36; ++i) H[i] = 0.0;
+    for (int i = 0; i < 6; ++i) gp[i] = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const int b = blks[k];
+        const double w = blk_w[b];
+        const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
+        for (int i = 0; i < 6; ++i) {
+            for (int j = i; j < 6; ++j) H[i * 6 + j] += w * acc[hidx(d.PL, i, j)];
+            gp[i] += w * acc[d.NH + i];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < i; ++j) H[i * 6 + j] = H[j * 6 + i];
+    if (init_scale)
+        for (int i = 0; i < 6; ++i) { const double s = 1.0 / (1.0 + sqrt(H[i * 6 + i])); scale2[i] = s * s; }
+    // gradient max-norm contribution (trust_region_minimizer.cc: inf-norm of the tangent gradient,
+    // or of Plus(x, -g) - x when the problem is bounds-constrained)
+    double gm = 0.0;
+    if (!constrained) {
+        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gp[i]));
+    } else {
+        const double ng[3] = {-gp[0], -gp[1], -gp[2]};
+        double qn[4];
+        quat_plus(xview7, ng, qn);
+        for (int i = 0; i < 4; ++i) gm = fmax(gm, fabs(qn[i] - xview7[i]));
+        for (int i = 3; i < 6; ++i) gm = fmax(gm, fabs(gp[i]));
+    }
+    *gmax = gm;
+    for (int i = 0; i < 6; ++i) {
+        D[i] = lm_diag(H[i * 6 + i], scale2[i], radius);
+        H[i * 6 + i] += D[i];
+    }
+    const bool ok = chol6(H);
+    for (int i = 0; i < 36; ++i) L[i] = H[i];
+    for (int i = 0; i < 6; ++i) y[i] = gp[i];
+    if (!ok) return false;
+    fwd6(L, y);
+    for (int k = 0; k < nb; ++k) {
+        const int b = blks[k];
+        const double w = blk_w[b];
+        const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
+        double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
+        for (int c = 0; c < d.PSH; ++c) {
+            double e[6];
+            for (int i = 0; i < 6; ++i) e[i] = w * acc[hidx(d.PL, i, 6 + c)];
+            fwd6(L, e);
+            for (int i = 0; i < 6; ++i) Z[i * d.PSH + c] = e[i];
+        }
+    }
+    return true;
+}
+
+// delta_p = -L^-T (y + sum_b Z_b delta_c[cols of b]); trial pose = Plus(x, delta_p).
+// step2 / xnorm2: the view's share of |x_trial - x|^2 and |x|^2 (ambient, 7 numbers).
+CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, const int32_t* blk_cam, const double* blk_Z,
+                              const double* delta_sh, bool fixed, const double* L, const double* y, const double* x7,
+                              double* delta_p, double* xt7, double* step2, double* xnorm2) {
+    double xn = 0.0;
+    for (int i = 0; i < 7; ++i) xn += x7[i] * x7[i];
+    *xnorm2 = fixed ? 0.0 : xn;  // constant blocks are not part of Ceres' reduced state vector
+    if (fixed) {
+        for (int i = 0; i < 6; ++i) delta_p[i] = 0.0;
+        for (int i = 0; i < 7; ++i) xt7[i] = x7[i];
+        *step2 = 0.0;
+        return;
+    }
+    double rhs[6];
+    for (int i = 0; i < 6; ++i) rhs[i] = y[i];
+    for (int k = 0; k < nb; ++k) {
+        const int b = blks[k];
+        const double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
+        const double* dc = delta_sh + blk_cam[b] * d.PC;
+        for (int i = 0; i < 6; ++i) {
+            double s = 0.0;
+            for (int c = 0; c < d.PSH; ++c) s += Z[i * d.PSH + c] * dc[c];
+            rhs[i] += s;
+        }
+    }
+    bwd6(L, rhs);
+    for (int i = 0; i < 6; ++i) delta_p[i] = -rhs[i];
+    quat_plus(x7, delta_p, xt7);
+    for (int i = 0; i < 3; ++i) xt7[4 + i] = x7[4 + i] + delta_p[3 + i];
+    double s2 = 0.0;
+    for (int i = 0; i < 7; ++i) s2 += (xt7[i] - x7[i]) * (xt7[i] - x7[i]);
+    *step2 = s2;
+}
+
+// Model-cost terms of one residual block for the step (delta_p, delta_c):
+//   gd = w g_b^T d_loc,   dHd = w d_loc^T H_b d_loc      (model change = -sum gd - 1/2 sum dHd)
+CBA_HD void model_block_body(const SchurDims& d, int cam, const double* acc, double w, const double* delta_p_view,
+                             const double* delta_sh, double* gd, double* dHd) {
+    double dl[24];
+    for (int lc = 0; lc < d.PL; ++lc) {
+        if (d.chain == CH_BUNDLE) dl[lc] = lc < 6 ? delta_sh[lc] : delta_sh[6 + cam * d.PC + (lc - 6)];
+        else dl[lc] = lc < 6 ? delta_p_view[lc] : delta_sh[cam * d.PC + (lc - 6)];
+    }
+    double g = 0.0, q = 0.0;
+    for (int i = 0; i < d.PL; ++i) {
+        g += acc[d.NH + i] * dl[i];
+        double s = 0.0;
+        for (int j = 0; j < d.PL; ++j) s += acc[hidx_sym(d.PL, i, j)] * dl[j];
+        q += dl[i] * s;
+    }
+    *gd = w * g;
+    *dHd = w * q;
+}
+
+}  // namespace cba

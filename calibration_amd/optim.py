@@ -337,7 +337,7 @@ class ReprojHandle:
         capi.check(self.lib, st)
         return cov
 
-    def set_allreduce(self, fn):
+    def set_allreduce(self, fn, n_ranks: int, rank: int):
         """fn(np.ndarray) sums the array in place across ranks (host buffers)."""
 
         def _cb(buf, count, _user):
@@ -349,7 +349,7 @@ class ReprojHandle:
                 return 1
 
         self._cb = capi.ALLREDUCE_FN(_cb)
-        capi.check(self.lib, self.lib.cba_reproj_set_allreduce(self.h, self._cb, None))
+        capi.check(self.lib, self.lib.cba_reproj_set_allreduce(self.h, self._cb, None, int(n_ranks), int(rank)))
 
     def init_rccl(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * capi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)

@@ -195,7 +195,7 @@ cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double*
 /* ---- multi-GPU: views sharded across ranks, one sum-all-reduce per LM linear solve ---------- */
 /* Host-buffer callback (any transport: gloo, MPI, ...): in-place sum of buf[count] over ranks. */
 typedef int32_t (*cba_allreduce_fn)(double* buf, int64_t count, void* user);
-cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user);
+cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank);
 /* RCCL-native: device-buffer ncclAllReduce on the handle's stream (xGMI within a node). */
 #define CBA_RCCL_UNIQUE_ID_BYTES 128
 cba_status cba_rccl_unique_id(uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES]);

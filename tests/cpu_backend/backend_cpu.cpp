@@ -1,0 +1,264 @@
+// tests/cpu_backend/backend_cpu.cpp — TEST-ONLY host implementation of cba::Backend.
+//
+// Runs the product's __host__ __device__ bodies (reproj_math.hpp, schur_math.hpp) in plain loops so
+// the host LM driver (lm_core.hpp), the Schur algebra, the masks/gauge rules, the covariance
+// assembly and the multi-rank all-reduce protocol can be tested without a GPU (gloo, world_size 2).
+// It lives under tests/, is built by the test suite, and is never linked into libcalibba.so.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../calibration_amd/csrc/lm_core.hpp"
+
+using namespace cba;
+
+namespace {
+
+struct CpuBackend final : Backend {
+    const Structure& s;
+    const cba_reproj_problem& d;
+    std::vector<double> intr[2], cam[2], target[2], view[2];
+    std::vector<double> bc, sd, blk_acc, blk_w, blk_Z, vL, vy, vD, vgp, vscale2, vdelta;
+    std::vector<int32_t> fixed;
+    SchurDims dims;
+
+    CpuBackend(const Structure& s_, const cba_reproj_problem& d_, const std::vector<double>& view0) : s(s_), d(d_) {
+        dims = SchurDims{s.PL, s.NH, s.NACC, s.PSH, s.PC, s.n_cams, s.chain};
+        for (int k = 0; k < 2; ++k) {
+            intr[k].assign(static_cast<size_t>(s.n_cams) * s.PI, 0.0);
+            cam[k].assign(static_cast<size_t>(s.n_cams) * 7, 0.0);
+            target[k].assign(7, 0.0);
+            view[k] = view0;
+        }
+        bc.assign(static_cast<size_t>(s.n_blocks) * BC_SIZE, 0.0);
+        sd.assign(static_cast<size_t>(s.n_cams) * SD_SIZE, 0.0);
+        blk_acc.assign(static_cast<size_t>(s.n_blocks) * s.NACC, 0.0);
+        blk_w.assign(s.n_blocks, 1.0);
+        blk_Z.assign(static_cast<size_t>(s.n_blocks) * 6 * s.PSH, 0.0);
+        vL.assign(static_cast<size_t>(s.n_views) * 36, 0.0);
+        vy.assign(static_cast<size_t>(s.n_views) * 6, 0.0);
+        vD = vy; vgp = vy; vdelta = vy;
+        vscale2.assign(static_cast<size_t>(s.n_views) * 6, 1.0);
+        fixed.assign(s.n_views, 0);
+    }
+    void set_view_fixed(const std::vector<int32_t>& f) override { fixed = f; }
+    void upload_shared(int which, const double* i, const double* c, const double* t) override {
+        std::memcpy(intr[which].data(), i, sizeof(double) * intr[which].size());
+        if (s.chain != CBA_CHAIN_INTRINSIC) std::memcpy(cam[which].data(), c, sizeof(double) * cam[which].size());
+        if (s.chain == CBA_CHAIN_BUNDLE) std::memcpy(target[which].data(), t, sizeof(double) * 7);
+    }
+    void consts(int which) {
+        for (int b = 0; b < s.n_blocks; ++b) {
+            const int c = s.blk_cam[b];
+            const double *pA, *pB = nullptr, *ax = nullptr;
+            if (s.chain == CBA_CHAIN_INTRINSIC) pA = &view[which][7 * static_cast<size_t>(s.blk_view[b])];
+            else if (s.chain == CBA_CHAIN_EXTRINSIC) { pA = &view[which][7 * static_cast<size_t>(s.blk_view[b])]; pB = &cam[which][7 * static_cast<size_t>(c)]; }
+            else { pA = target[which].data(); pB = &cam[which][7 * static_cast<size_t>(c)]; ax = d.blk_b_T_g + 12 * static_cast<size_t>(b); }
+            double* o = &bc[static_cast<size_t>(b) * BC_SIZE];
+            if (s.chain == CBA_CHAIN_INTRINSIC) block_consts<CH_INTRINSIC>(pA, pB, ax, o);
+            else if (s.chain == CBA_CHAIN_EXTRINSIC) block_consts<CH_EXTRINSIC>(pA, pB, ax, o);
+            else block_consts<CH_BUNDLE>(pA, pB, ax, o);
+        }
+        if (s.model == CBA_CAMERA_SCHEIMPFLUG)
+            for (int c = 0; c < s.n_cams; ++c) scheimpflug_consts(&intr[which][static_cast<size_t>(c) * 12], &sd[static_cast<size_t>(c) * SD_SIZE]);
+    }
+    template <int CHAIN, int MODEL>
+    void mode_b(int which) {
+        constexpr int PL = LocalCols<CHAIN, MODEL>::value;
+        for (int b = 0; b < s.n_blocks; ++b) {
+            double* acc = &blk_acc[static_cast<size_t>(b) * s.NACC];
+            for (int e = 0; e < s.NACC; ++e) acc[e] = 0.0;
+            const int c = s.blk_cam[b];
+            for (int64_t i = s.blk_offset[b]; i < s.blk_offset[b + 1]; ++i) {
+                double rr[2], Ju[PL], Jv[PL];
+                reproj_point<CHAIN, MODEL>(&bc[static_cast<size_t>(b) * BC_SIZE], &intr[which][static_cast<size_t>(c) * s.PI],
+                                           &sd[static_cast<size_t>(c) * SD_SIZE], d.X[i], d.Y[i], d.u[i], d.v[i], rr, Ju, Jv);
+                int e = 0;
+                for (int a = 0; a < PL; ++a)
+                    for (int bb = a; bb < PL; ++bb) acc[e++] += Ju[a] * Ju[bb] + Jv[a] * Jv[bb];
+                for (int a = 0; a < PL; ++a) acc[s.NH + a] += Ju[a] * rr[0] + Jv[a] * rr[1];
+                acc[s.NH + PL] += rr[0] * rr[0] + rr[1] * rr[1];
+            }
+        }
+    }
+    double block_s(int which, int b) {
+        const int c = s.blk_cam[b];
+        double ss = 0;
+        for (int64_t i = s.blk_offset[b]; i < s.blk_offset[b + 1]; ++i) {
+            double rr[2];
+            if (s.model == CBA_CAMERA_SCHEIMPFLUG)
+                reproj_residual<CAM_SCHEIMPFLUG>(&bc[static_cast<size_t>(b) * BC_SIZE], &intr[which][static_cast<size_t>(c) * s.PI], &sd[static_cast<size_t>(c) * SD_SIZE], d.X[i], d.Y[i], d.u[i], d.v[i], rr);
+            else
+                reproj_residual<CAM_PINHOLE_BC>(&bc[static_cast<size_t>(b) * BC_SIZE], &intr[which][static_cast<size_t>(c) * s.PI], &sd[static_cast<size_t>(c) * SD_SIZE], d.X[i], d.Y[i], d.u[i], d.v[i], rr);
+            ss += rr[0] * rr[0] + rr[1] * rr[1];
+        }
+        return ss;
+    }
+    void normal_eq(double hub, std::vector<double>& cam_acc, double cost2[2]) override {
+        consts(0);
+        switch (s.chain * 2 + s.model) {
+            case 0: mode_b<CH_INTRINSIC, CAM_PINHOLE_BC>(0); break;
+            case 1: mode_b<CH_INTRINSIC, CAM_SCHEIMPFLUG>(0); break;
+            case 2: mode_b<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); break;
+            case 3: mode_b<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); break;
+            case 4: mode_b<CH_BUNDLE, CAM_PINHOLE_BC>(0); break;
+            default: mode_b<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); break;
+        }
+        cost2[0] = cost2[1] = 0;
+        cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
+        for (int b = 0; b < s.n_blocks; ++b) {
+            const double ss = blk_acc[static_cast<size_t>(b) * s.NACC + s.NH + s.PL];
+            double rho, w;
+            huber(ss, hub, &rho, &w);
+            blk_w[b] = w;
+            cost2[0] += 0.5 * rho;
+            cost2[1] += ss;
+        }
+        for (int c = 0; c < s.n_cams; ++c)
+            for (int64_t k = s.cam_off[c]; k < s.cam_off[c + 1]; ++k) {
+                const int b = s.cam_blk[k];
+                for (int e = 0; e < s.NACC; ++e) cam_acc[static_cast<size_t>(c) * s.NACC + e] += blk_w[b] * blk_acc[static_cast<size_t>(b) * s.NACC + e];
+            }
+    }
+    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
+               int* nfail) override {
+        const int n = s.nsh;
+        S.assign(static_cast<size_t>(n) * n, 0.0);
+        g.assign(n, 0.0);
+        *gmax_priv = 0;
+        *nfail = 0;
+        for (int v = 0; v < s.n_views; ++v) {
+            const int nb = static_cast<int>(s.link_off[v + 1] - s.link_off[v]);
+            const int32_t* blks = s.link_blk.data() + s.link_off[v];
+            double gm = 0;
+            const bool ok = schur_view_body(dims, nb, blks, blk_acc.data(), blk_w.data(), fixed[v] != 0, radius, init_scale, constrained,
+                                            &view[0][7 * static_cast<size_t>(v)], &vscale2[6 * static_cast<size_t>(v)], &vL[36 * static_cast<size_t>(v)],
+                                            &vy[6 * static_cast<size_t>(v)], &vD[6 * static_cast<size_t>(v)], &vgp[6 * static_cast<size_t>(v)], blk_Z.data(), &gm);
+            if (!ok) { ++*nfail; continue; }
+            *gmax_priv = std::max(*gmax_priv, gm);
+            // S += Zv^T Zv, g += Zv^T y
+            for (int k1 = 0; k1 < nb; ++k1) {
+                const int b1 = blks[k1];
+                const double* Z1 = &blk_Z[static_cast<size_t>(b1) * 6 * s.PSH];
+                const int g1 = s.blk_cam[b1] * s.PC;
+                for (int c1 = 0; c1 < s.PSH; ++c1) {
+                    double sy = 0;
+                    for (int k = 0; k < 6; ++k) sy += Z1[k * s.PSH + c1] * vy[6 * static_cast<size_t>(v) + k];
+                    g[g1 + c1] += sy;
+                    for (int k2 = 0; k2 < nb; ++k2) {
+                        const int b2 = blks[k2];
+                        const double* Z2 = &blk_Z[static_cast<size_t>(b2) * 6 * s.PSH];
+                        const int g2 = s.blk_cam[b2] * s.PC;
+                        for (int c2 = 0; c2 < s.PSH; ++c2) {
+                            double sum = 0;
+                            for (int k = 0; k < 6; ++k) sum += Z1[k * s.PSH + c1] * Z2[k * s.PSH + c2];
+                            S[static_cast<size_t>(g1 + c1) * n + g2 + c2] += sum;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    void trial(const double* delta_sh, double hub, TrialStats* st) override {
+        *st = TrialStats();
+        for (int v = 0; v < s.n_views; ++v) {
+            const int nb = static_cast<int>(s.link_off[v + 1] - s.link_off[v]);
+            double s2, x2;
+            backsub_view_body(dims, nb, s.link_blk.data() + s.link_off[v], s.blk_cam.data(), blk_Z.data(), delta_sh, fixed[v] != 0,
+                              &vL[36 * static_cast<size_t>(v)], &vy[6 * static_cast<size_t>(v)], &view[0][7 * static_cast<size_t>(v)],
+                              &vdelta[6 * static_cast<size_t>(v)], &view[1][7 * static_cast<size_t>(v)], &s2, &x2);
+            st->step2 += s2;
+            st->xnorm2 += x2;
+        }
+        for (int b = 0; b < s.n_blocks; ++b) {
+            double gd, dHd;
+            const double* dp = s.has_private() ? &vdelta[6 * static_cast<size_t>(s.blk_view[b])] : nullptr;
+            model_block_body(dims, s.blk_cam[b], &blk_acc[static_cast<size_t>(b) * s.NACC], blk_w[b], dp, delta_sh, &gd, &dHd);
+            st->gd += gd;
+            st->dHd += dHd;
+        }
+        consts(1);
+        for (int b = 0; b < s.n_blocks; ++b) {
+            double rho, w;
+            huber(block_s(1, b), hub, &rho, &w);
+            st->cost += 0.5 * rho;
+        }
+    }
+    void accept() override { view[0] = view[1]; }
+    void download_private(double* vp) override { std::memcpy(vp, view[0].data(), sizeof(double) * view[0].size()); }
+    void download_blocks(std::vector<double>& acc, std::vector<double>& w) override { acc = blk_acc; w = blk_w; }
+};
+
+struct Session {
+    Structure s;
+    std::vector<double> intr, cam, view, target;
+};
+
+thread_local std::string g_err;
+
+template <typename F>
+int guarded(F&& f) {
+    try { f(); return CBA_OK; }
+    catch (const std::invalid_argument& e) { g_err = e.what(); return CBA_ERR_INVALID_ARGUMENT; }
+    catch (const std::runtime_error& e) { g_err = e.what(); return CBA_ERR_RUNTIME; }
+    catch (const std::exception& e) { g_err = e.what(); return CBA_ERR_INTERNAL; }
+}
+
+void load(const cba_reproj_problem& d, Session& ss) {
+    build_structure(d, ss.s);
+    ss.intr.assign(d.intr, d.intr + static_cast<size_t>(d.n_cams) * ss.s.PI);
+    if (d.chain != CBA_CHAIN_INTRINSIC) ss.cam.assign(d.cam_pose, d.cam_pose + 7 * static_cast<size_t>(d.n_cams));
+    else ss.cam.assign(7 * static_cast<size_t>(d.n_cams), 0.0);
+    if (d.chain != CBA_CHAIN_BUNDLE && d.n_views > 0) ss.view.assign(d.view_pose, d.view_pose + 7 * static_cast<size_t>(d.n_views));
+    if (d.chain == CBA_CHAIN_BUNDLE) ss.target.assign(d.target_pose, d.target_pose + 7);
+    else ss.target.assign(7, 0.0);
+}
+void store(const cba_reproj_problem& d, const Session& ss) {
+    std::memcpy(d.intr, ss.intr.data(), sizeof(double) * ss.intr.size());
+    if (d.chain != CBA_CHAIN_INTRINSIC) std::memcpy(d.cam_pose, ss.cam.data(), sizeof(double) * ss.cam.size());
+    if (d.chain != CBA_CHAIN_BUNDLE && d.n_views > 0) std::memcpy(d.view_pose, ss.view.data(), sizeof(double) * ss.view.size());
+    if (d.chain == CBA_CHAIN_BUNDLE) std::memcpy(d.target_pose, ss.target.data(), sizeof(double) * 7);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hm_last_error(void) { return g_err.c_str(); }
+
+// LM solve with the product's host driver + the CPU test backend.  allreduce may be NULL.
+int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
+                    cba_summary* out) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        AllReduce ar = [&](double* buf, int64_t n) {
+            if (fn && fn(buf, n, user) != 0) throw std::runtime_error("allreduce callback failed");
+        };
+        LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, ar, n_ranks, rank);
+        drv.solve(*o, out);
+        store(*d, ss);
+    });
+}
+
+int64_t hm_reproj_covariance_dim(const cba_reproj_problem* d) {
+    Session ss;
+    try { load(*d, ss); } catch (...) { return -1; }
+    CpuBackend be(ss.s, *d, ss.view);
+    LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+    return drv.covariance_dim();
+}
+
+int hm_reproj_covariance(const cba_reproj_problem* d, const cba_options* o, double* cov) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+        drv.covariance(*o, cov);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Test helpers: ctypes bindings of the oracle (oracle/_build/liboracle.so) and of the test-only host
+build of the product's math (tests/cpu_backend/_build/libhostmath.so), option builders, metrics."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from calibration_amd import capi
+from calibration_amd.capi import CbaOptions, CbaReprojProblem, CbaSummary, c_double_p, dptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+HOSTMATH_SO = os.path.join(ROOT, "tests", "cpu_backend", "_build", "libhostmath.so")
+
+PP = C.POINTER(CbaReprojProblem)
+PO = C.POINTER(CbaOptions)
+PS = C.POINTER(CbaSummary)
+
+
+def load_oracle():
+    o = C.CDLL(ORACLE_SO)
+    o.orc_last_error.restype = C.c_char_p
+    o.orc_project.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p]
+    o.orc_project.restype = None
+    o.orc_reproj_eval.argtypes = [PP, c_double_p, c_double_p, c_double_p]
+    o.orc_reproj_cost.argtypes = [PP, C.c_double, c_double_p]
+    o.orc_reproj_solve.argtypes = [PP, PO, C.c_int, PS]
+    o.orc_reproj_covariance_dim.argtypes = [PP]
+    o.orc_reproj_covariance_dim.restype = C.c_int64
+    o.orc_reproj_covariance.argtypes = [PP, PO, c_double_p]
+    o.orc_reproj_bench_eval.argtypes = [PP, C.c_int, C.c_int, C.c_int, C.c_int]
+    o.orc_reproj_bench_eval.restype = C.c_double
+    o.orc_axxb_eval.argtypes = [c_double_p] * 10
+    o.orc_axxb_eval.restype = None
+    o.orc_axxb_solve.argtypes = [C.c_int, c_double_p, c_double_p, PO, PS, c_double_p]
+    o.orc_quat_to_rotmat.argtypes = [c_double_p, c_double_p]
+    o.orc_rotmat_to_quat.argtypes = [c_double_p, c_double_p]
+    o.orc_quat_plus.argtypes = [c_double_p, c_double_p, c_double_p]
+    return o
+
+
+def load_hostmath():
+    h = C.CDLL(HOSTMATH_SO)
+    h.hm_last_error.restype = C.c_char_p
+    h.hm_reproj_eval.argtypes = [PP, c_double_p, c_double_p]
+    h.hm_reproj_solve.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, PS]
+    h.hm_reproj_covariance_dim.argtypes = [PP]
+    h.hm_reproj_covariance_dim.restype = C.c_int64
+    h.hm_reproj_covariance.argtypes = [PP, PO, c_double_p]
+    return h
+
+
+def options(**kw) -> CbaOptions:
+    """Reference defaults (optimize.h:24-33) unless overridden."""
+    o = CbaOptions()
+    o.optimizer = 0
+    o.max_iterations = 1000
+    o.huber_delta = 1.0
+    o.epsilon = 1e-9
+    o.compute_covariance = 1
+    o.verbose = 0
+    o.optimize_intrinsics = 1
+    o.optimize_skew = 0
+    o.optimize_extrinsics = 1
+    o.optimize_target_pose = 1
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+def local_cols(flat) -> int:
+    return (6 if flat.chain == capi.CHAIN_INTRINSIC else 12) + (12 if flat.model == capi.CAMERA_SCHEIMPFLUG else 10)
+
+
+def oracle_eval(orc, flat):
+    d = flat.struct()
+    n, p = flat.n_obs, local_cols(flat)
+    r = np.zeros(2 * n)
+    J = np.zeros((2 * n, p))
+    st = orc.orc_reproj_eval(C.byref(d), dptr(r), dptr(J), dptr(None))
+    assert st == 0, orc.orc_last_error()
+    return r, J
+
+
+def oracle_solve(orc, flat, opts, threads=4) -> CbaSummary:
+    d = flat.struct()
+    s = CbaSummary()
+    st = orc.orc_reproj_solve(C.byref(d), C.byref(opts), threads, C.byref(s))
+    assert st == 0, orc.orc_last_error()
+    return s
+
+
+def oracle_cost(orc, flat, huber=1.0) -> float:
+    d = flat.struct()
+    c = C.c_double(0)
+    assert orc.orc_reproj_cost(C.byref(d), huber, C.byref(c)) == 0
+    return c.value
+
+
+def oracle_covariance(orc, flat, opts):
+    d = flat.struct()
+    n = int(orc.orc_reproj_covariance_dim(C.byref(d)))
+    cov = np.zeros((n, n))
+    st = orc.orc_reproj_covariance(C.byref(d), C.byref(opts), dptr(cov))
+    return cov if st == 0 else None
+
+
+def oracle_block_normal_eq(orc, flat):
+    """Per block [upper(J^T J) | J^T r | |r|^2] from the oracle's autodiff Jacobian."""
+    r, J = oracle_eval(orc, flat)
+    p = J.shape[1]
+    iu = np.triu_indices(p)
+    out = []
+    for b in range(flat.n_blocks):
+        lo, hi = 2 * flat.blk_offset[b], 2 * flat.blk_offset[b + 1]
+        Jb, rb = J[lo:hi], r[lo:hi]
+        H = Jb.T @ Jb
+        out.append(np.concatenate([H[iu], Jb.T @ rb, [rb @ rb]]))
+    return np.stack(out)
+
+
+def rel_diff(a, b) -> float:
+    if a is None or b is None:
+        return 0.0
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(a))).max()) if a.size else 0.0
+
+
+def param_diff(fa, fb) -> float:
+    """max |dp| / max(|p|, 1) over every parameter block (SURVEY.md §8d parity metric)."""
+    return max(rel_diff(fa.intr, fb.intr), rel_diff(fa.cam_pose, fb.cam_pose), rel_diff(fa.view_pose, fb.view_pose),
+               rel_diff(fa.target_pose, fb.target_pose))
+
+
+def clone(flat):
+    import copy
+
+    return copy.deepcopy(flat)

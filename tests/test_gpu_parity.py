@@ -1,0 +1,167 @@
+"""GPU tier: the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+
+Tolerances (fp64):
+  residuals            |dr| <= 1e-9 px absolute (values ~1e1..1e3 px)
+  Jacobian entries     |dJ| <= 1e-9 * max(1, |J|)
+  block normal eq.     relative 1e-10 of the block's largest entry (different summation order)
+  LM final parameters  max|dp|/max(|p|,1) <= 1e-9 for pinhole + Brown-Conrady (north-star bar);
+                       1e-6 for the Scheimpflug model, whose tau/principal-point near-degeneracy
+                       (condition number ~1e8) amplifies rounding between two correct solvers.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from calibration_amd import capi, optim, synth
+from tests import helpers
+from tests.helpers import options
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {
+    "intr": lambda m, **k: synth.scene_intrinsics(7, model=m, **k),
+    "ext": lambda m, **k: synth.scene_extrinsics(5, 3, model=m, **k),
+    "bundle": lambda m, **k: synth.scene_bundle(9, 2, model=m, distortion=True, **k),
+}
+
+
+def _perturb_intr(sc, seed=1):
+    sc.flat.intr[...] = sc.gt_intr * (1 + 0.01 * np.random.default_rng(seed).uniform(-1, 1, sc.gt_intr.shape))
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("kind", ["intr", "ext", "bundle"])
+def test_mode_a_residual_and_jacobian(gpu_lib, oracle, kind, model):
+    sc = SCENES[kind](model)
+    _perturb_intr(sc)
+    r0, J0 = helpers.oracle_eval(oracle, sc.flat)
+    with optim.ReprojHandle(sc.flat) as h:
+        h.eval()
+        r1, J1 = h.eval_fetch()
+    assert np.abs(r0 - r1).max() <= 1e-9
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+
+
+def test_mode_a_odd_and_tiny_views(gpu_lib, oracle):
+    """ragged input: views of 1, 2, 3, 127, 128, 129, 257 points (tile / padding edges)."""
+    rng = np.random.default_rng(3)
+    sc = synth.scene_intrinsics(7, rows=17, cols=17)
+    f = sc.flat
+    keep = [1, 2, 3, 127, 128, 129, 257]
+    views = []
+    for b, n in enumerate(keep):
+        lo = f.blk_offset[b]
+        views.append(np.stack([f.X[lo:lo + n], f.Y[lo:lo + n], f.u[lo:lo + n], f.v[lo:lo + n]], axis=1))
+    flat = optim.FlatProblem(f.chain, f.model, views, np.zeros(7, np.int32), np.arange(7, dtype=np.int32), f.intr, None,
+                             f.view_pose, None)
+    r0, J0 = helpers.oracle_eval(oracle, flat)
+    with optim.ReprojHandle(flat) as h:
+        h.eval()
+        r1, J1 = h.eval_fetch()
+        assert h.n_obs == sum(keep)
+        nb = h.block_normal_eq()
+        c1 = h.cost(1.0)
+    assert np.abs(r0 - r1).max() <= 1e-9
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+    ref = helpers.oracle_block_normal_eq(oracle, flat)
+    assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
+    assert abs(c1 - helpers.oracle_cost(oracle, flat)) <= 1e-10 * max(1.0, c1)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("kind", ["intr", "ext", "bundle"])
+def test_mode_b_block_normal_equations_and_cost(gpu_lib, oracle, kind, model):
+    sc = SCENES[kind](model, noise_px=0.3)
+    _perturb_intr(sc)
+    ref = helpers.oracle_block_normal_eq(oracle, sc.flat)
+    with optim.ReprojHandle(sc.flat) as h:
+        nb = h.block_normal_eq()
+        for delta in (1.0, -1.0, 25.0):
+            c = h.cost(delta)
+            c0 = helpers.oracle_cost(oracle, sc.flat, delta)
+            assert abs(c - c0) <= 1e-11 * max(1.0, abs(c0))
+    assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
+
+
+def test_empty_view_and_bad_index_are_invalid_argument(gpu_lib):
+    sc = synth.scene_intrinsics(5)
+    f = sc.flat
+    f.blk_offset[2] = f.blk_offset[1]  # block 1 empty -> "No observations provided"
+    with pytest.raises(capi.CbaInvalidArgument):
+        optim.ReprojHandle(f)
+    sc = synth.scene_extrinsics(3, 2)
+    sc.flat.blk_cam[0] = 5
+    with pytest.raises(capi.CbaInvalidArgument):
+        optim.ReprojHandle(sc.flat)
+
+
+CASES = [
+    ("intr", 0, {}, {}, 1e-9),
+    ("intr", 0, dict(noise_px=0.2), {}, 1e-9),
+    ("intr", 0, {}, dict(optimize_skew=1), 1e-9),
+    ("intr", 1, {}, {}, 1e-6),
+    ("ext", 0, {}, {}, 1e-9),
+    ("ext", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
+    ("ext", 0, dict(noise_px=0.2), dict(optimize_extrinsics=0), 1e-9),
+    ("ext", 1, {}, {}, 1e-6),
+    ("bundle", 0, {}, dict(optimize_intrinsics=1), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, huber_delta=-1.0), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0, optimize_target_pose=0), 1e-9),
+    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-6),
+]
+
+
+@pytest.mark.parametrize("kind,model,skw,okw,tol", CASES)
+def test_lm_solve_matches_oracle(gpu_lib, oracle, kind, model, skw, okw, tol):
+    mk = {"intr": lambda: synth.scene_intrinsics(12, model=model, **skw),
+          "ext": lambda: synth.scene_extrinsics(6, 3, model=model, **skw),
+          "bundle": lambda: synth.scene_bundle(16, 2, model=model, **skw)}[kind]
+    a, b = mk(), mk()
+    o = options(**okw)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+    assert sb.termination == sa.termination
+    assert abs(sb.iterations - sa.iterations) <= 2
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * max(1.0, sa.final_cost) + 1e-15
+    assert helpers.param_diff(a.flat, b.flat) <= tol
+
+
+def test_covariance_matches_oracle(gpu_lib, oracle):
+    for mk, okw in ((lambda: synth.scene_intrinsics(6, noise_px=0.2), {}),
+                    (lambda: synth.scene_extrinsics(4, 2, noise_px=0.2), {}),
+                    (lambda: synth.scene_bundle(10, 2, noise_px=0.2), dict(optimize_intrinsics=1))):
+        a, b = mk(), mk()
+        o = options(**okw)
+        helpers.oracle_solve(oracle, a.flat, o)
+        cov0 = helpers.oracle_covariance(oracle, a.flat, o)
+        with optim.ReprojHandle(b.flat) as h:
+            h.solve(o)
+            cov1 = h.covariance(o)
+        assert cov0 is not None and cov1 is not None
+        assert cov0.shape == cov1.shape
+        scale = np.sqrt(np.outer(np.abs(np.diag(cov0)) + 1e-300, np.abs(np.diag(cov0)) + 1e-300))
+        assert (np.abs(cov0 - cov1) / np.maximum(scale, 1e-30)).max() <= 1e-5
+
+
+def test_large_random_scene_properties(gpu_lib):
+    """Size-independent properties at a size the oracle would take minutes for: J^T r from Mode A
+    equals the Mode B gradient; cost equals 1/2 |r|^2 without loss; evaluation is deterministic."""
+    sc = synth.scene_intrinsics(40, rows=50, cols=50, noise_px=0.2)
+    with optim.ReprojHandle(sc.flat) as h:
+        h.eval()
+        r, J = h.eval_fetch()
+        nb = h.block_normal_eq()
+        nb2 = h.block_normal_eq()
+        c = h.cost(-1.0)
+    p = J.shape[1]
+    nh = p * (p + 1) // 2
+    g_modeb = nb[:, nh:nh + p]
+    for b in range(sc.flat.n_blocks):
+        lo, hi = 2 * sc.flat.blk_offset[b], 2 * sc.flat.blk_offset[b + 1]
+        g = J[lo:hi].T @ r[lo:hi]
+        assert np.abs(g - g_modeb[b]).max() <= 1e-9 * max(1.0, np.abs(g).max())
+    assert abs(c - 0.5 * float(r @ r)) <= 1e-10 * c
+    assert np.array_equal(nb, nb2)
