@@ -63,7 +63,7 @@ def main():
 
     # ---- synthetic scene: this rank's shard of the (world * views)-view problem ----------------------
     t_gen = time.time()
-    scene = synth.scene_intrinsics(args.views, rows=args.grid, cols=args.grid, spacing=0.2 / args.grid, seed=7 + rank,
+    scene = synth.scene_intrinsics(args.views, rows=args.grid, cols=args.grid, spacing=0.8 / args.grid, seed=7 + rank,
                                    noise_px=0.2, first_view_global=rank * args.views)
     flat = scene.flat
     init_intr, init_view = flat.intr.copy(), flat.view_pose.copy()
@@ -93,9 +93,17 @@ def main():
 
     bytes_per_obs = 8 * (4 + 2 + 2 * P)  # 4 loads + 2 residual + 2P Jacobian stores, fp64
     achieved = bytes_per_obs * n_obs / (ms_kernel * 1e-3) / 1e9
+    # HBM traffic of one k_eval launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    # rocprofv3 --pmc runs of this same command; gfx950 FETCH_SIZE correction applied), same unit as `achieved`
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_k_eval.json")
+    if os.path.exists(pmc_path) and args.views == 1000 and args.grid == 100:
+        pmc = json.load(open(pmc_path))
+        traffic = pmc["hbm_bytes_per_launch"] / (ms_kernel * 1e-3) / 1e9
+        traffic_src = "profiles/pmc_k_eval.json"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_eval<INTRINSIC,PINHOLE_BC>",
-                "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     lm = None
@@ -128,7 +136,8 @@ def main():
 
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
         orc = helpers.load_oracle()
-        cores = os.cpu_count() or 1
+        # the GPU box gives a 1-GPU job a 16-core CPU share whatever os.cpu_count() says
+        cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         sample_views = min(args.views, max(cores, 32))
         d = flat.struct()
         t_probe = orc.orc_reproj_bench_eval(C.byref(d), 0, sample_views, cores, 1)

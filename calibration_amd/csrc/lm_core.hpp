@@ -213,6 +213,15 @@ class LMDriver {
             ar_(buf.data(), static_cast<int64_t>(buf.size()));
             assemble_shared(buf, Hcc, gc);
         }
+        // ceres::Covariance (SPARSE_QR): a column is dependent when its R diagonal is below
+        // 20 (m + n) eps max_j |J_j| (SuiteSparseQR default tolerance, third-party, restated)
+        double cmax = 0;
+        for (int i = 0; i < n; ++i) cmax = std::max(cmax, std::sqrt(Hcc[static_cast<size_t>(i) * n + i]));
+        for (int v = 0; v < s_.n_views; ++v)
+            for (int64_t k = s_.link_off[v]; k < s_.link_off[v + 1]; ++k)
+                for (int i = 0; i < 6; ++i)
+                    cmax = std::max(cmax, std::sqrt(w[s_.link_blk[k]] * acc[static_cast<size_t>(s_.link_blk[k]) * NACC + hidx(PL, i, i)]));
+        const double rank_tol = 20.0 * static_cast<double>(2 * s_.n_obs + n + 6 * s_.n_views) * 2.220446049250313e-16 * cmax;
         // compact active shared indices
         std::vector<int> act;
         for (int i = 0; i < n; ++i)
@@ -246,6 +255,8 @@ class LMDriver {
             }
             std::vector<double> L = H;
             if (!chol_inplace(L, 6)) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
+            for (int i = 0; i < 6; ++i)
+                if (L[i * 6 + i] <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
             std::vector<double> Hi;
             chol_inverse(L, 6, Hi);
             std::memcpy(&Hinv[static_cast<size_t>(fv) * 36], Hi.data(), sizeof(double) * 36);
@@ -268,9 +279,9 @@ class LMDriver {
         std::vector<double> Lc = S0, Scc;
         if (na > 0) {
             if (!chol_inplace(Lc, na)) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
-            double dmin = 1e300, dmax = 0;
-            for (int i = 0; i < na; ++i) { dmin = std::min(dmin, Lc[static_cast<size_t>(i) * na + i]); dmax = std::max(dmax, Lc[static_cast<size_t>(i) * na + i]); }
-            if ((dmin / dmax) * (dmin / dmax) < 1e-14) throw std::runtime_error("covariance: rank deficient Jacobian (condition number)");
+            double dmin = 1e300;
+            for (int i = 0; i < na; ++i) dmin = std::min(dmin, Lc[static_cast<size_t>(i) * na + i]);
+            if (dmin <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
             chol_inverse(Lc, na, Scc);
         }
         // tangent covariance: [shared active (na) | free views (6 each)]

@@ -437,10 +437,18 @@ class Problem {
         const int n = ntan;
         std::vector<double> L = H;
         if (n > 0 && !cholesky_inplace(L, n)) return false;
-        // reject near-singular systems (min_reciprocal_condition_number = 1e-14)
-        double dmin = 1e300, dmax = 0;
-        for (int i = 0; i < n; ++i) { dmin = std::min(dmin, L[static_cast<size_t>(i) * n + i]); dmax = std::max(dmax, L[static_cast<size_t>(i) * n + i]); }
-        if (n > 0 && (dmin / dmax) * (dmin / dmax) < 1e-14) return false;
+        // ceres::Covariance defaults to SPARSE_QR; SuiteSparseQR declares a column dependent when its
+        // R diagonal is below 20 (m + n) eps max_j |J_j| (third-party default, restated).
+        {
+            size_t m = 0;
+            for (auto& rb : residuals) m += static_cast<size_t>(rb->nres);
+            double cmax = 0, dmin = 1e300;
+            for (int i = 0; i < n; ++i) {
+                cmax = std::max(cmax, std::sqrt(H[static_cast<size_t>(i) * n + i]));
+                dmin = std::min(dmin, L[static_cast<size_t>(i) * n + i]);
+            }
+            if (n > 0 && dmin <= 20.0 * static_cast<double>(m + n) * 2.220446049250313e-16 * cmax) return false;
+        }
         std::vector<double> Sig(static_cast<size_t>(n) * n, 0.0), e(n);
         for (int c = 0; c < n; ++c) {
             std::fill(e.begin(), e.end(), 0.0); e[c] = 1.0;
