@@ -103,10 +103,11 @@ def random_view_poses(n_views: int, rng, dist=2.0, max_tilt_deg=25.0, jitter=0.1
     return out
 
 
-def render_view(intr, c_T_t, grid, noise_px=0.0, rng=None) -> np.ndarray:
-    """render_pixels (tests/unit/utils.h:233-250) for one view -> PlanarView (N,4)."""
+def render_view(intr, c_T_t, grid, noise_px=0.0, rng=None, cull=True) -> np.ndarray:
+    """render_pixels (tests/unit/utils.h:233-250, culls Pc.z <= 1e-6) for one view -> PlanarView (N,4);
+    cull=False is make_bundle_observations (utils.h:137-160), which projects every point."""
     Pc = transform_points(c_T_t, grid)
-    keep = Pc[:, 2] > 1e-6
+    keep = Pc[:, 2] > 1e-6 if cull else np.ones(len(Pc), dtype=bool)
     uv = project(intr, Pc[keep])
     if noise_px > 0 and rng is not None:
         uv = uv + rng.normal(0.0, noise_px, size=uv.shape)

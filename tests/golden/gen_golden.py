@@ -1,0 +1,418 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/ (run from the repo root:
+``python tests/golden/gen_golden.py``).  The reference has no stored Ceres outputs and cannot be
+built or imported in this image (C++ needing Ceres/Eigen), so the fixtures come from
+INDEPENDENT derivations of the formulas in the reference's headers:
+
+reproj_jacobians.json  residuals + tangent Jacobians of small problems for every chain x camera
+                       model, differentiated by the COMPLEX-STEP method on a numpy restatement of the
+                       forward model (calibration_amd/synth.py: pinhole.h:102-107, distortion.h:91-116,
+                       camera_matrix.h:41-46, scheimpflug.h:139-181; chains per intrinsicresidual.h,
+                       extrinsicsresidual.h, bundleresidual.h).  Shares no code with the oracle's dual
+                       numbers nor with the kernels' analytic derivatives.
+axxb_pairs.json        AX=XB residuals (handeyeresidual.h:25-49) and tangent Jacobians by 60-digit
+                       mpmath central differences, rotation log via acos/skew-part (not Eigen's
+                       quaternion route).
+kat_scenes.json        the reference's ground-truth-recovery scenes (tests/unit/*_test.cpp recipes,
+                       tests/unit/utils.h generators) with numpy's MT19937 stream: inputs, initial
+                       guesses, ground truth and the reference's tolerances.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from calibration_amd import synth  # noqa: E402
+from calibration_amd.geometry import (axis_angle_to_R, inv, make_pose, pose_from_matrix, quat_to_rotmat)  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------
+# complex-step Jacobians
+# ------------------------------------------------------------------------------------------------
+def quat_mul(a, b):
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
+    ])
+
+
+def pose_plus_first_order(p7, d6):
+    """QuaternionManifold Plus to first order (exact for the complex step): q+ = [1, d] (x) q."""
+    q = quat_mul(np.array([1.0 + 0j, d6[0], d6[1], d6[2]]), p7[:4].astype(complex))
+    return np.concatenate([q, p7[4:] + d6[3:]])
+
+
+def chain_Rt(chain, pA, pB, bTg):
+    RA, tA = quat_to_rotmat(pA[:4]), pA[4:]
+    if chain == 0:
+        return RA, tA
+    RB, tB = quat_to_rotmat(pB[:4]), pB[4:]
+    if chain == 1:  # c_T_t = c_T_r * r_T_t
+        return RB @ RA, RB @ tA + tB
+    Rbg, tbg = bTg[:9].reshape(3, 3), bTg[9:]
+    Rcg, tcg = RB.T, -RB.T @ tB
+    Rgb, tgb = Rbg.T, -Rbg.T @ tbg
+    Rcb, tcb = Rcg @ Rgb, Rcg @ tgb + tcg
+    return Rcb @ RA, Rcb @ tA + tcb
+
+
+def forward(chain, intr, pA, pB, bTg, XY):
+    R, t = chain_Rt(chain, pA, pB, bTg)
+    P = XY[:, 0:1] * R[:, 0][None, :] + XY[:, 1:2] * R[:, 1][None, :] + t[None, :]
+    return synth.project(intr, P)
+
+
+def complex_step_block(chain, intr, pA, pB, bTg, XY, uv):
+    h = 1e-30
+    PI = intr.shape[0]
+    ncol = (6 if chain == 0 else 12) + PI
+    n = XY.shape[0]
+    r = (forward(chain, intr, pA, pB, bTg, XY) - uv).reshape(-1)
+    J = np.zeros((2 * n, ncol))
+    for k in range(ncol):
+        d = np.zeros(ncol, dtype=complex)
+        d[k] = 1j * h
+        pa = pose_plus_first_order(pA, d[0:6])
+        off = 6
+        pb = pB
+        if chain != 0:
+            pb = pose_plus_first_order(pB, d[6:12])
+            off = 12
+        it = intr.astype(complex) + d[off:]
+        f = forward(chain, it, pa, pb, bTg, XY)
+        J[:, k] = (f.imag / h).reshape(-1)
+    return r, J
+
+
+def gen_reproj_jacobians():
+    rng = np.random.RandomState(20251004)
+    out = []
+    for chain in (0, 1, 2):
+        for model in (0, 1):
+            intr = synth.camera_gt(model) * (1 + 0.02 * rng.uniform(-1, 1, 12 if model else 10))
+            intr[4] = 0.3  # non-zero skew so its column is exercised
+            nb = 3
+            XY = synth.make_target_grid(3, 4, 0.05) + 0.003 * rng.uniform(-1, 1, (12, 2))
+            blocks = []
+            if chain == 0:
+                poses = [pose_from_matrix(T) for T in synth.random_view_poses(nb, np.random.default_rng(5))]
+            elif chain == 1:
+                c_T_r = synth.ring_cameras(2)[1]
+                poses = [pose_from_matrix(T) for T in synth.random_view_poses(nb, np.random.default_rng(6))]
+                pB = pose_from_matrix(c_T_r)
+            else:
+                b_T_t = make_pose([0.5, -0.1, 0.8], [1.0, 0.2, 0.0], 0.25)
+                g_T_c = make_pose([0.03, 0.0, 0.12], [0.0, 1.0, 0.1], 0.14)
+                pB = pose_from_matrix(g_T_c)
+            for b in range(nb):
+                bTg = np.zeros(12)
+                if chain == 0:
+                    pA, pb = poses[b], None
+                elif chain == 1:
+                    pA, pb = poses[b], pB
+                else:
+                    pA, pb = pose_from_matrix(b_T_t), pB
+                    c_T_t = synth.random_view_poses(1, np.random.default_rng(10 + b), dist=1.0)[0]
+                    T = b_T_t @ inv(c_T_t) @ inv(g_T_c)
+                    bTg = np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]])
+                uv_gt = forward(chain, intr, pA, pb, bTg, XY).real
+                uv = uv_gt + rng.normal(0, 0.5, uv_gt.shape)
+                r, J = complex_step_block(chain, intr, pA, pb, bTg, XY, uv)
+                blocks.append(dict(pA=pA.tolist(), pB=None if pb is None else pb.tolist(), bTg=bTg.tolist(), XY=XY.tolist(),
+                                   uv=uv.tolist(), r=r.tolist(), J=J.tolist()))
+            out.append(dict(chain=chain, model=model, intr=intr.tolist(), blocks=blocks))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# AX = XB with mpmath
+# ------------------------------------------------------------------------------------------------
+def gen_axxb():
+    import mpmath as mp
+
+    mp.mp.dps = 60
+
+    def q2R(q):
+        w, x, y, z = q
+        return mp.matrix([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def logR(R):
+        c = (R[0, 0] + R[1, 1] + R[2, 2] - 1) / 2
+        th = mp.acos(c)
+        if th == 0:
+            return mp.matrix([0, 0, 0])
+        k = th / (2 * mp.sin(th))
+        return mp.matrix([k * (R[2, 1] - R[1, 2]), k * (R[0, 2] - R[2, 0]), k * (R[1, 0] - R[0, 1])])
+
+    def qmul(a, b):
+        return [a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]]
+
+    def resid(q, t, RA, RB, tA, tB, d6):
+        n = mp.sqrt(d6[0] ** 2 + d6[1] ** 2 + d6[2] ** 2)
+        if n == 0:
+            qd = [mp.mpf(1), 0, 0, 0]
+        else:
+            s = mp.sin(n) / n
+            qd = [mp.cos(n), s * d6[0], s * d6[1], s * d6[2]]
+        qq = qmul(qd, q)
+        tt = [t[i] + d6[3 + i] for i in range(3)]
+        RX = q2R(qq)
+        RS = RA * RX * RB.T * RX.T
+        rr = logR(RS)
+        te = (RA - mp.eye(3)) * mp.matrix(tt) - (RX * tB - tA)
+        return [rr[0], rr[1], rr[2], te[0], te[1], te[2]]
+
+    rng = np.random.RandomState(99)
+    out = []
+    for _ in range(6):
+        X = make_pose(rng.uniform(-0.1, 0.1, 3), rng.normal(size=3), 0.2)
+        A = make_pose(rng.uniform(-0.2, 0.2, 3), rng.normal(size=3), rng.uniform(0.1, 0.5))
+        B = inv(X) @ A @ X
+        # perturb so the residual is not zero
+        B = make_pose(rng.uniform(-0.01, 0.01, 3), rng.normal(size=3), 0.03) @ B
+        p = pose_from_matrix(X)
+        q = [mp.mpf(float(v)) for v in p[:4]]
+        t = [mp.mpf(float(v)) for v in p[4:]]
+        RA = mp.matrix(A[:3, :3].tolist()); RB = mp.matrix(B[:3, :3].tolist())
+        tA = mp.matrix(A[:3, 3].tolist()); tB = mp.matrix(B[:3, 3].tolist())
+        r0 = resid(q, t, RA, RB, tA, tB, [mp.mpf(0)] * 6)
+        h = mp.mpf(10) ** -25
+        J = [[0.0] * 6 for _ in range(6)]
+        for k in range(6):
+            dp = [mp.mpf(0)] * 6; dm = [mp.mpf(0)] * 6
+            dp[k] = h; dm[k] = -h
+            rp = resid(q, t, RA, RB, tA, tB, dp); rm = resid(q, t, RA, RB, tA, tB, dm)
+            for i in range(6):
+                J[i][k] = float((rp[i] - rm[i]) / (2 * h))
+        out.append(dict(pose=p.tolist(), RA=A[:3, :3].reshape(-1).tolist(), RB=B[:3, :3].reshape(-1).tolist(),
+                        tA=A[:3, 3].tolist(), tB=B[:3, 3].tolist(), r=[float(v) for v in r0], J=J))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# reference KAT scenes
+# ------------------------------------------------------------------------------------------------
+class RNG:
+    """tests/unit/utils.h:163-181 on numpy's MT19937 (engine identical to std::mt19937; the
+    real-number transform and C++'s unspecified argument evaluation order are not reproduced, so the
+    random poses differ from the reference binary's — irrelevant for ground-truth-recovery KATs)."""
+
+    def __init__(self, seed):
+        self.g = np.random.RandomState(seed)
+
+    def uni(self, a, b):
+        return float(self.g.uniform(a, b))
+
+    def rand_unit_axis(self):
+        z = self.uni(-1.0, 1.0)
+        t = self.uni(0.0, 2.0 * np.pi)
+        r = np.sqrt(1.0 - z * z)
+        return np.array([r * np.cos(t), r * np.sin(t), z])
+
+    def gauss(self, s, size=None):
+        return self.g.normal(0.0, s, size)
+
+
+def sim_sequence(n, rng):  # SimulatedHandEye::make_sequence, utils.h:203-221
+    T = np.eye(4)
+    out = []
+    for k in range(n):
+        out.append(T.copy())
+        if k + 1 < n:
+            ang = np.deg2rad(rng.uni(5.0, 25.0))
+            ax = rng.rand_unit_axis()
+            dt = np.array([rng.uni(-0.10, 0.10), rng.uni(-0.10, 0.10), rng.uni(-0.10, 0.10)])
+            T = T @ make_pose(dt, ax, ang)
+    return out
+
+
+def make_circle_poses(n, radius, z0, z_step, rot_step, axis_z=1.0):  # utils.h:81-96
+    out = []
+    for i in range(n):
+        a = i * 2.0 * np.pi / n
+        out.append(make_pose([radius * np.cos(a), radius * np.sin(a), z0 + z_step * i], [np.cos(a), np.sin(a), axis_z], rot_step * i))
+    return out
+
+
+def cam10(fx, fy, cx, cy, skew=0.0, dist=(0, 0, 0, 0, 0)):
+    return np.array([fx, fy, cx, cy, skew, *dist], dtype=float)
+
+
+def render(cam, c_T_t, grid, cull=True):
+    return synth.render_view(cam, c_T_t, grid, cull=cull)
+
+
+def kat_scenes():
+    S = {}
+    # ---- OptimizeIntrinsics.* (intrinsics_optimize_test.cpp:8-113) ---------------------------------
+    for name, seed, skew, init_f, opt_skew, tol_skew in (("intrinsics_noskew", 7, 0.0, (0.97, 1.03, 5.0, -4.0), False, 1e-9),
+                                                         ("intrinsics_skew", 5, 0.001, (0.95, 1.05, 10.0, -6.0), True, 1e-8)):
+        rng = RNG(seed)
+        cam = cam10(1000, 1005, 640, 360, skew)
+        b_T_t = make_pose([0, 0, 2.0], [0, 0, 1], 0.0)
+        seq = sim_sequence(15, rng)
+        grid = synth.make_target_grid(8, 11, 0.02)
+        views = [render(cam, inv(T) @ b_T_t, grid) for T in seq]
+        cam0 = cam.copy(); cam0[0] *= init_f[0]; cam0[1] *= init_f[1]; cam0[2] += init_f[2]; cam0[3] += init_f[3]; cam0[4] = 0.0
+        S[name] = dict(kind="intrinsics", views=[v.tolist() for v in views], cam_gt=cam.tolist(), cam_init=cam0.tolist(),
+                       optimize_skew=opt_skew, tol_K=1e-6, tol_skew=tol_skew, max_final_cost=1e-6,
+                       ref="tests/unit/intrinsics_optimize_test.cpp:8-61,63-113")
+    # ---- OptimizeBundle.RecoversXAndIntrinsics_NoDistortion[Skew] (bundle_test.cpp:9-154) -----------
+    for name, skew, opt_skew, tol_skew in (("bundle_noskew", 0.0, False, 1e-9), ("bundle_skew", 0.001, True, 1e-6)):
+        rng = RNG(7)
+        g_T_c = make_pose([0.03, 0.0, 0.12], [0, 1, 0], np.deg2rad(8.0))
+        b_T_t = make_pose([0.5, -0.1, 0.8], [1, 0, 0], np.deg2rad(14.0))
+        cam = cam10(1000, 1005, 640, 360, skew)
+        seq = sim_sequence(25, rng)
+        grid = synth.make_target_grid(8, 11, 0.02)
+        obs = [dict(view=render(cam, inv(g_T_c) @ inv(T) @ b_T_t, grid).tolist(), b_T_g=T.tolist(), cam=0) for T in seq]
+        cam0 = cam10(1000 * 0.97, 1005 * 1.03, 645.0, 356.0, skew if not opt_skew else 0.0)
+        g0 = g_T_c.copy()
+        g0[:3, 3] += [-0.01, 0.006, -0.004]
+        g0[:3, :3] = axis_angle_to_R([0.3, 0.7, -0.2], np.deg2rad(2.0)) @ g0[:3, :3]
+        S[name] = dict(kind="bundle", obs=obs, cams_gt=[cam.tolist()], cams_init=[cam0.tolist()], g_T_c_gt=[g_T_c.tolist()],
+                       g_T_c_init=[g0.tolist()], b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+                       opts=dict(optimize_intrinsics=True, optimize_skew=opt_skew, huber_delta=-1.0),
+                       tol_rot_deg=1e-6, tol_trans=1e-6, tol_K=1e-6, tol_skew=tol_skew, ref="tests/unit/bundle_test.cpp:9-154")
+    # ---- ReprojectionRefine.DistortionRecoveryOptional (bundle_test.cpp:156-210) ---------------------
+    cam = cam10(900, 905, 640, 360, 0.0, (-0.12, 0.02, 0.0005, -0.0007, 0.001))
+    g_T_c = make_pose([0.03, 0.0, 0.12], [0, 1, 0], np.deg2rad(8.0))
+    b_T_t = make_pose([0.5, -0.1, 80], [1, 0, 0], np.deg2rad(14.0))
+    grid = synth.make_target_grid(7, 10, 0.022)
+    # The target sits 80 m away, so the cumulative random gripper rotations swing it far off-axis.
+    # With numpy's stream seed 137 puts one view ~89 deg off-axis (|x| ~ 55, outside any sane range
+    # of a degree-7 radial polynomial); the reference's own stream evidently does not.  Use the
+    # first seed >= 137 whose views all stay within normalised radius 1 (recorded as seed_used).
+    seed = 137
+    while True:
+        rng = RNG(seed)
+        seq = sim_sequence(22, rng)
+        worst = 0.0
+        for T in seq:
+            Pc = synth.transform_points(inv(g_T_c) @ inv(T) @ b_T_t, grid)
+            worst = max(worst, float(np.max(np.hypot(Pc[:, 0], Pc[:, 1]) / np.abs(Pc[:, 2]))) if np.all(Pc[:, 2] > 1e-6) else 1e9)
+        if worst < 1.0:
+            break
+        seed += 1
+    obs = [dict(view=render(cam, inv(g_T_c) @ inv(T) @ b_T_t, grid).tolist(), b_T_g=T.tolist(), cam=0) for T in seq]
+    cam0 = cam.copy(); cam0[5:] = 0
+    X0 = g_T_c.copy(); X0[:3, 3] += [0.01, 0.006, -0.003]
+    X0[:3, :3] = axis_angle_to_R([0.1, 0.8, 0.1], np.deg2rad(2.0)) @ X0[:3, :3]
+    S["bundle_distortion"] = dict(kind="bundle", obs=obs, cams_gt=[cam.tolist()], cams_init=[cam0.tolist()], g_T_c_gt=[g_T_c.tolist()],
+                                  g_T_c_init=[X0.tolist()], b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+                                  opts=dict(optimize_intrinsics=True, optimize_skew=False, huber_delta=1.0),
+                                  tol_rot_deg=0.1, tol_trans=0.02, tol_dist=1e-5, seed_used=seed,
+                                  ref="tests/unit/bundle_test.cpp:156-210")
+    # ---- OptimizeBundle.SingleCameraHandEye / TwoCameras (bundle_test.cpp:229-349) -------------------
+    cam = cam10(100, 100, 64, 48)
+    g0c = make_pose([0.1, 0.0, 0.05], [0, 1, 0], 0.05)
+    b_T_t = make_pose([0.2, 0, 0], [0, 0, 1], 0.0)
+    pts9 = np.array([[-0.1, -0.1], [0.1, -0.1], [0.1, 0.1], [-0.1, 0.1], [0.5, 0.5], [-1, -1], [2, 2], [2.5, 0.5], [9, 0]], float)
+    poses = make_circle_poses(8, 0.1, 0.3, 0.05, 0.1, 0.5)
+    obs = [dict(view=render(cam, inv(g0c) @ inv(T) @ b_T_t, pts9, False).tolist(), b_T_g=T.tolist(), cam=0) for T in poses]
+    gi = g0c.copy(); gi[:3, 3] += [0.01, -0.01, 0.02]
+    S["bundle_single_handeye"] = dict(kind="bundle", obs=obs, cams_gt=[cam.tolist()], cams_init=[cam.tolist()], g_T_c_gt=[g0c.tolist()],
+                                      g_T_c_init=[gi.tolist()], b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+                                      opts=dict(optimize_intrinsics=False, optimize_target_pose=False, optimize_hand_eye=True),
+                                      tol_rot_rad=1e-3, tol_trans=1e-3, max_final_cost=0.01, ref="tests/unit/bundle_test.cpp:229-263")
+    pts8 = pts9[:8]
+    c1_T_c0 = make_pose([0.05, 0, 0], [0, 0, 1], 0.1)
+    g1c = g0c @ inv(c1_T_c0)
+    obs = []
+    for T in poses:
+        for ci, g in enumerate((g0c, g1c)):
+            obs.append(dict(view=render(cam, inv(g) @ inv(T) @ b_T_t, pts8, False).tolist(), b_T_g=T.tolist(), cam=ci))
+    g1i = g1c.copy(); g1i[:3, 3] += [0.01, -0.01, 0.0]; g1i[:3, :3] = g1c[:3, :3] @ axis_angle_to_R([0, 0, 1], 0.01)
+    g0i = g0c.copy(); g0i[:3, 3] += [-0.01, 0.02, -0.02]
+    S["bundle_two_cameras"] = dict(kind="bundle", obs=obs, cams_gt=[cam.tolist()] * 2, cams_init=[cam.tolist()] * 2,
+                                   g_T_c_gt=[g0c.tolist(), g1c.tolist()], g_T_c_init=[g0i.tolist(), g1i.tolist()],
+                                   b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+                                   opts=dict(optimize_intrinsics=False, optimize_target_pose=False, optimize_hand_eye=True),
+                                   tol_rot_rad=1e-3, tol_trans=1e-3, ref="tests/unit/bundle_test.cpp:291-349")
+    # ---- ScheimpflugBundle.* (scheimpflug_bundle_test.cpp:13-94) --------------------------------------
+    sc = np.concatenate([cam10(100, 100, 64, 48), [0.02, -0.015]])
+    pts = np.array([[-0.1, -0.1], [0.1, -0.1], [0.1, 0.1], [-0.1, 0.1], [0.05, 0], [-0.05, 0], [0, 0.05], [0, -0.05]], float)
+    obs = [dict(view=render(sc, inv(g0c) @ inv(T) @ b_T_t, pts, False).tolist(), b_T_g=T.tolist(), cam=0) for T in poses]
+    sc0 = sc.copy(); sc0[10] += 0.01; sc0[11] -= 0.01
+    S["scheimpflug_intrinsics_fixed_handeye"] = dict(
+        kind="bundle", obs=obs, cams_gt=[sc.tolist()], cams_init=[sc0.tolist()], g_T_c_gt=[g0c.tolist()], g_T_c_init=[g0c.tolist()],
+        b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+        opts=dict(optimize_intrinsics=True, optimize_target_pose=False, optimize_hand_eye=False), tol_rot_rad=1e-6, tol_trans=1e-6,
+        tol_tau=1e-6, ref="tests/unit/scheimpflug_bundle_test.cpp:13-56")
+    S["scheimpflug_handeye_fixed_intrinsics"] = dict(
+        kind="bundle", obs=obs, cams_gt=[sc.tolist()], cams_init=[sc.tolist()], g_T_c_gt=[g0c.tolist()], g_T_c_init=[gi.tolist()],
+        b_T_t_gt=b_T_t.tolist(), b_T_t_init=b_T_t.tolist(),
+        opts=dict(optimize_intrinsics=False, optimize_target_pose=False, optimize_hand_eye=True), tol_rot_rad=1e-6, tol_trans=1e-6,
+        tol_tau=1e-6, ref="tests/unit/scheimpflug_bundle_test.cpp:58-94")
+    # ---- Extrinsics.* (extrinsics_test.cpp:9-199) -----------------------------------------------------
+    kcam = cam10(100, 100, 0, 0)
+    cam_gt = [np.eye(4), make_pose([1, 0, 0], [0, 0, 1], 0.0)]
+    tg3 = [make_pose([0, 0, 5], [0, 0, 1], 0.0), make_pose([0.5, -0.2, 4.0], [0, 1, 0], 0.3), make_pose([-0.3, 0.4, 6.0], [-1, 0, 0], 0.2)]
+    pts4 = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], float)
+    pts8e = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5], [-1, -1], [2, 2], [2.5, 0.5]], float)
+
+    def ext_views(targets, pts):
+        return [[render(kcam, cam_gt[c] @ T, pts, False).tolist() for c in range(2)] for T in targets]
+
+    cam_init = [np.eye(4), make_pose([1.2, -0.1, 0.05], [0, 0, 1], 0.05)]
+    tg_init = [tg3[0] @ make_pose([0.1, 0, 0], [0, 0, 1], 0.02), tg3[1] @ make_pose([-0.05, 0.1, 0.05], [0, -1, 0], 0.03),
+               tg3[2] @ make_pose([0.02, -0.02, -0.1], [1, 0, 0], 0.01)]
+    S["extrinsics_poses"] = dict(kind="extrinsics", views=ext_views(tg3, pts4), cams_gt=[kcam.tolist()] * 2, cams_init=[kcam.tolist()] * 2,
+                                 c_T_r_gt=[T.tolist() for T in cam_gt], c_T_r_init=[T.tolist() for T in cam_init],
+                                 r_T_t_gt=[T.tolist() for T in tg3], r_T_t_init=[T.tolist() for T in tg_init],
+                                 opts=dict(optimize_intrinsics=False), tol_pose=1e-3, max_final_cost=1e-6,
+                                 ref="tests/unit/extrinsics_test.cpp:9-73")
+    tg2 = tg3[:2]
+    ci = [cam10(90, 95, 1, -1), cam10(105, 98, -0.5, 0.5)]
+    # the reference seeds with estimate_extrinsic_dlt (host linear code, out of scope); a perturbed
+    # ground truth of the same quality stands in, with target pose 0 anchored as in the test
+    seed_c = [np.eye(4), make_pose([1.03, 0.02, -0.02], [0, 1, 0], 0.01)]
+    seed_t = [tg2[0], tg2[1] @ make_pose([0.02, -0.01, 0.03], [1, 0, 0], 0.01)]
+    S["extrinsics_all_parameters"] = dict(kind="extrinsics", views=ext_views(tg2, pts8e), cams_gt=[kcam.tolist()] * 2,
+                                          cams_init=[c.tolist() for c in ci], c_T_r_gt=[T.tolist() for T in cam_gt],
+                                          c_T_r_init=[T.tolist() for T in seed_c], r_T_t_gt=[T.tolist() for T in tg2],
+                                          r_T_t_init=[T.tolist() for T in seed_t], opts=dict(), tol_f=1e-3, tol_pose=1e-3,
+                                          max_final_cost=1e-6, covariance_trace_positive=True,
+                                          ref="tests/unit/extrinsics_test.cpp:75-140")
+    seed_t2 = [make_pose([0, 0, 3.0], [0, 0, 1], 0.0), seed_t[1]]  # wrong scale on the gauge pose
+    S["extrinsics_first_target_fixed"] = dict(kind="extrinsics", views=ext_views(tg2, pts8e), cams_gt=[kcam.tolist()] * 2,
+                                              cams_init=[c.tolist() for c in ci], c_T_r_gt=[T.tolist() for T in cam_gt],
+                                              c_T_r_init=[T.tolist() for T in seed_c], r_T_t_gt=[T.tolist() for T in tg2],
+                                              r_T_t_init=[T.tolist() for T in seed_t2], opts=dict(), gauge_tol=1e-12, min_final_cost=0.1,
+                                              ref="tests/unit/extrinsics_test.cpp:142-199")
+    # ---- CeresAXXBRefine.ImprovesOverInitializer (handeye_test.cpp:101-152) ----------------------------
+    rng = RNG(2024)
+    X = make_pose([0.02, -0.01, 0.09], rng.rand_unit_axis(), np.deg2rad(10.0))
+    bTt = make_pose([0.25, 0.05, 0.55], rng.rand_unit_axis(), np.deg2rad(18.0))
+    seq = sim_sequence(18, rng)
+    cTt = [inv(X) @ inv(T) @ bTt for T in seq]
+    X0 = X.copy()
+    X0[:3, :3] = axis_angle_to_R(rng.rand_unit_axis(), np.deg2rad(2.0)) @ X0[:3, :3]
+    X0[:3, 3] += [0.01, -0.005, 0.004]
+    S["axxb_refine"] = dict(kind="handeye", b_T_g=[T.tolist() for T in seq], c_T_t=[T.tolist() for T in cTt], X_gt=X.tolist(),
+                            X_init=X0.tolist(), opts=dict(max_iterations=60, huber_delta=1.0), tol_rot_deg=0.05, tol_trans=0.002,
+                            ref="tests/unit/handeye_test.cpp:101-152")
+    return S
+
+
+def main():
+    json.dump(gen_reproj_jacobians(), open(os.path.join(HERE, "reproj_jacobians.json"), "w"))
+    json.dump(gen_axxb(), open(os.path.join(HERE, "axxb_pairs.json"), "w"))
+    json.dump(kat_scenes(), open(os.path.join(HERE, "kat_scenes.json"), "w"))
+    for f in ("reproj_jacobians.json", "axxb_pairs.json", "kat_scenes.json"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -137,3 +137,34 @@ def clone(flat):
     import copy
 
     return copy.deepcopy(flat)
+
+
+# ---- AX = XB pair construction (src/estimation/linear/handeyedlt.cpp:11-81; host linear code) ------
+def log_so3(R):
+    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) * 0.5))
+    th = np.arccos(c)
+    if th < 1e-12:
+        return np.zeros(3)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) * (0.5 / np.sin(th))
+    return w * th
+
+
+def build_all_pairs(b_T_g, c_T_t, min_angle_deg=0.5, reject_axis_parallel=True, axis_parallel_eps=1e-3):
+    """-> (n_pairs, 24) rows [RA(9) RB(9) tA(3) tB(3)]."""
+    from calibration_amd.geometry import inv
+
+    out = []
+    n = len(b_T_g)
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            A = inv(b_T_g[i]) @ b_T_g[j]
+            B = c_T_t[i] @ inv(c_T_t[j])
+            al, be = log_so3(A[:3, :3]), log_so3(B[:3, :3])
+            na, nb = np.linalg.norm(al), np.linalg.norm(be)
+            if min(na, nb) < np.deg2rad(min_angle_deg):
+                continue
+            if reject_axis_parallel and na >= 1e-9 and nb >= 1e-9:
+                if np.linalg.norm(np.cross(al / na, be / nb)) < axis_parallel_eps:
+                    continue
+            out.append(np.concatenate([A[:3, :3].reshape(-1), B[:3, :3].reshape(-1), A[:3, 3], B[:3, 3]]))
+    return np.asarray(out)

@@ -1,0 +1,241 @@
+"""CPU tier: host logic of the product, with no GPU.
+
+* the C ABI: libcalibba.so loads, exports every symbol include/calibba.h declares, option defaults and
+  pose helpers match the reference's conventions, validation errors map to the reference's exception
+  types, and every compute entry point fails LOUDLY (CBA_ERR_NO_DEVICE) when no GPU is visible;
+* the device arithmetic (reproj_math.hpp, the code the HIP kernels run per lane) compiled for the host:
+  analytic Jacobian == the oracle's autodiff Jacobian to 1e-12 relative;
+* the host LM driver / Schur algebra / covariance assembly (lm_core.hpp + schur_math.hpp) on the
+  test-only CPU backend against the oracle's independent dense solver.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from calibration_amd import capi, optim, synth
+from calibration_amd.capi import CbaOptions, CbaSummary, dptr
+from calibration_amd.geometry import make_pose, pose_from_matrix, pose_to_matrix
+from tests import helpers
+from tests.helpers import options
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "calibba.h")).read()
+    declared = set(re.findall(r"\b(cba_[a-z0-9_]+)\s*\(", header)) - {"cba_allreduce_fn"}
+    assert len(declared) >= 29
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libcalibba.so does not export {name}"
+    assert declared == set(capi.PROTOTYPES), "capi.PROTOTYPES and calibba.h disagree"
+
+
+def test_option_defaults_match_reference(lib):
+    o = CbaOptions()
+    lib.cba_options_default(C.byref(o))
+    # optimize.h:24-33
+    assert (o.optimizer, o.huber_delta, o.epsilon, o.max_iterations, o.compute_covariance, o.verbose) == (0, 1.0, 1e-9, 1000, 1, 0)
+    assert lib.cba_intrinsics_size(0) == 10 and lib.cba_intrinsics_size(1) == 12  # pinhole.h:118, scheimpflug.h:236
+    assert [lib.cba_local_columns(c, m) for c in (0, 1, 2) for m in (0, 1)] == [16, 18, 22, 24, 22, 24]
+    assert lib.cba_version().decode() == "0.1.0"
+
+
+def test_pose_helpers_match_eigen_conventions(lib):
+    rng = np.random.default_rng(0)
+    for ang in (0.0, 0.3, 2.9, 3.14):  # includes the trace <= 0 branch of Eigen's matrix->quaternion
+        T = make_pose(rng.uniform(-1, 1, 3), rng.normal(size=3), ang)
+        p = np.zeros(7)
+        lib.cba_pose_from_matrix(dptr(np.ascontiguousarray(T.T.reshape(-1))), dptr(p))
+        assert np.allclose(p, pose_from_matrix(T), atol=1e-15)
+        assert abs(np.linalg.norm(p[:4]) - 1) < 1e-12
+        m = np.zeros(16)
+        lib.cba_pose_to_matrix(dptr(np.concatenate([2.5 * p[:4], p[4:]])), dptr(m))  # restore_pose normalises
+        assert np.allclose(m.reshape(4, 4).T, T, atol=1e-12)
+        assert np.allclose(pose_to_matrix(p), T, atol=1e-12)
+
+
+def test_validation_errors_map_to_reference_exceptions(lib):
+    # empty view: IntrinsicResidual::create throws std::invalid_argument (intrinsicresidual.h:38-40)
+    f = synth.scene_intrinsics(5).flat
+    f.blk_offset[2] = f.blk_offset[1]
+    with pytest.raises(capi.CbaInvalidArgument, match="No observations provided"):
+        optim.ReprojHandle(f)
+    f = synth.scene_extrinsics(3, 2).flat
+    f.blk_view[0] = 17
+    with pytest.raises(capi.CbaInvalidArgument):
+        optim.ReprojHandle(f)
+    # optimize_intrinsics: < 4 views (intrinsics.cpp:92-96)
+    sc = synth.scene_intrinsics(3)
+    views = [np.stack([sc.flat.X[:5], sc.flat.Y[:5], sc.flat.u[:5], sc.flat.v[:5]], 1)] * 3
+    with pytest.raises(ValueError, match="at least 4"):
+        optim.optimize_intrinsics(views, sc.flat.intr[0], [np.eye(4)] * 3)
+    o, s = options(), CbaSummary()
+    off = np.array([0, 5, 10, 15], dtype=np.int64)
+    st = lib.cba_optimize_intrinsics(0, 3, capi.i64ptr(off), dptr(sc.flat.X), dptr(sc.flat.Y), dptr(sc.flat.u), dptr(sc.flat.v),
+                                     dptr(sc.flat.intr), dptr(sc.flat.view_pose), C.byref(o), C.byref(s), dptr(None))
+    assert st == capi.CBA_ERR_INVALID_ARGUMENT and b"at least 4" in lib.cba_last_error()
+    # optimize_extrinsics: pose vector sizes (extrinsics.cpp:162-172)
+    with pytest.raises(ValueError, match="Incompatible pose vector sizes"):
+        optim.optimize_extrinsics([[views[0], views[0]]], [sc.flat.intr[0]] * 2, [np.eye(4)], [np.eye(4)])
+    # optimize_bundle: no cameras / no observations (bundle.cpp:139-144)
+    with pytest.raises(ValueError, match="No camera intrinsics provided"):
+        optim.optimize_bundle([optim.BundleObservation(views[0], np.eye(4), 0)], [], [], np.eye(4))
+    with pytest.raises(ValueError, match="No observations provided"):
+        optim.optimize_bundle([], [sc.flat.intr[0]], [np.eye(4)], np.eye(4))
+    # OptimizeBundle.InputValidation (bundle_test.cpp:212-227): two default (empty) observations
+    with pytest.raises(ValueError, match="No observations provided"):
+        optim.optimize_bundle([optim.BundleObservation(np.zeros((0, 4)), np.eye(4), 0)] * 2, [sc.flat.intr[0]] * 2, [np.eye(4)], np.eye(4))
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(lib):
+    if lib.cba_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.CbaError) as ei:
+        optim.ReprojHandle(synth.scene_intrinsics(5).flat)
+    assert ei.value.status == capi.CBA_ERR_NO_DEVICE
+    with pytest.raises(capi.CbaError) as ei:
+        optim.optimize_handeye([np.eye(4)] * 3, [np.eye(4)] * 3, np.eye(4))
+    assert ei.value.status == capi.CBA_ERR_NO_DEVICE
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "calibration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hpp", ".hip", ".cpp", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/_ref", ""), f"{fn} references the oracle"
+
+
+# ---- device arithmetic on the host -------------------------------------------------------------------
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("kind", ["intr", "ext", "bundle"])
+def test_analytic_jacobian_equals_autodiff(oracle, hostmath, kind, model):
+    sc = {"intr": lambda: synth.scene_intrinsics(6, model=model, noise_px=0.3),
+          "ext": lambda: synth.scene_extrinsics(4, 3, model=model, noise_px=0.3),
+          "bundle": lambda: synth.scene_bundle(6, 2, model=model, distortion=True, noise_px=0.3)}[kind]()
+    f = sc.flat
+    f.intr[...] = sc.gt_intr * (1 + 0.01 * np.random.default_rng(1).uniform(-1, 1, sc.gt_intr.shape))
+    f.intr.reshape(-1, f.intr.shape[-1])[:, 4] = 0.2
+    r0, J0 = helpers.oracle_eval(oracle, f)
+    d = f.struct()
+    r1, J1 = np.zeros_like(r0), np.zeros_like(J0)
+    assert hostmath.hm_reproj_eval(C.byref(d), dptr(r1), dptr(J1)) == 0
+    assert np.abs(r0 - r1).max() <= 1e-10
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-12
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_device_math_matches_complex_step_golden(hostmath, idx):
+    import json
+
+    from tests.test_oracle_kat import _flat_from_golden
+
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "reproj_jacobians.json")))[idx]
+    for b in range(len(case["blocks"])):
+        flat = _flat_from_golden(case, b)
+        d = flat.struct()
+        r0, J0 = np.asarray(case["blocks"][b]["r"]), np.asarray(case["blocks"][b]["J"])
+        r, J = np.zeros_like(r0), np.zeros_like(J0)
+        assert hostmath.hm_reproj_eval(C.byref(d), dptr(r), dptr(J)) == 0
+        assert np.abs(r - r0).max() <= 1e-9
+        assert (np.abs(J - J0) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+
+
+# ---- host LM driver on the CPU test backend ----------------------------------------------------------
+def hm_solve(hostmath, flat, o) -> CbaSummary:
+    d = flat.struct()
+    s = CbaSummary()
+    st = hostmath.hm_reproj_solve(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, C.byref(s))
+    assert st == 0, hostmath.hm_last_error()
+    return s
+
+
+LM_CASES = [
+    ("intr", 0, {}, {}, 1e-9), ("intr", 0, dict(noise_px=0.2), {}, 1e-9), ("intr", 0, {}, dict(optimize_skew=1), 5e-9),
+    ("intr", 1, dict(noise_px=0.2), {}, 1e-6),
+    ("ext", 0, {}, {}, 1e-9), ("ext", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
+    ("ext", 0, dict(noise_px=0.2), dict(optimize_extrinsics=0), 1e-9), ("ext", 1, {}, dict(optimize_intrinsics=0), 1e-6),
+    ("bundle", 0, {}, dict(optimize_intrinsics=1), 1e-9), ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, huber_delta=-1.0), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0, optimize_target_pose=0), 1e-9),
+    ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, optimize_extrinsics=0), 1e-9),
+    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-6),
+]
+
+
+@pytest.mark.parametrize("kind,model,skw,okw,tol", LM_CASES)
+def test_schur_lm_driver_matches_dense_oracle(oracle, hostmath, kind, model, skw, okw, tol):
+    # 0.8 m x 0.56 m board (spacing 0.08): fills the field of view, so the 1e-9 bar is not eaten by the
+    # conditioning of a target that covers 8 % of the image (the reference's 0.02 m test geometry)
+    mk = {"intr": lambda: synth.scene_intrinsics(12, model=model, spacing=0.08, **skw),
+          "ext": lambda: synth.scene_extrinsics(6, 3, model=model, spacing=0.08, **skw),
+          "bundle": lambda: synth.scene_bundle(16, 2, model=model, spacing=0.04, **skw)}[kind]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **okw)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sb.termination == sa.termination
+    assert abs(sb.iterations - sa.iterations) <= 2
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * max(1.0, sa.final_cost) + 1e-15
+    assert helpers.param_diff(a.flat, b.flat) <= tol
+
+
+def test_lm_semantics(oracle, hostmath):
+    # max_iterations hit => NO_CONVERGENCE => success False (ceresutils.h:42)
+    sc = synth.scene_intrinsics(8, noise_px=0.2)
+    s = hm_solve(hostmath, sc.flat, options(max_iterations=2))
+    assert s.termination == capi.TERM_NO_CONVERGENCE and not s.success and s.iterations == 2
+    # starting at the optimum of noise-free data => gradient tolerance at iteration 0
+    sc = synth.scene_intrinsics(8, init="gt")
+    s = hm_solve(hostmath, sc.flat, options())
+    assert s.success and s.iterations == 0 and s.final_cost < 1e-12
+    # gauge: with optimize_intrinsics the first target pose never moves (extrinsics.cpp:123-126)
+    sc = synth.scene_extrinsics(5, 2, noise_px=0.2)
+    v0 = sc.flat.view_pose.reshape(-1, 7)[0].copy()
+    c0 = sc.flat.cam_pose.reshape(-1, 7)[0].copy()
+    hm_solve(hostmath, sc.flat, options())
+    assert np.array_equal(sc.flat.view_pose.reshape(-1, 7)[0], v0) and np.array_equal(sc.flat.cam_pose.reshape(-1, 7)[0], c0)
+    # skew stays put unless optimize_skew (SubsetManifold)
+    sc = synth.scene_intrinsics(8, noise_px=0.2)
+    sc.flat.intr[0, 4] = 0.123
+    hm_solve(hostmath, sc.flat, options())
+    assert sc.flat.intr[0, 4] == 0.123
+
+
+@pytest.mark.parametrize("kind", ["intr", "ext", "ext_nointr", "bundle", "bundle_fixed"])
+def test_covariance_assembly_matches_oracle(oracle, hostmath, kind):
+    mk, okw = {"intr": (lambda: synth.scene_intrinsics(6, noise_px=0.2), {}),
+               "ext": (lambda: synth.scene_extrinsics(4, 2, noise_px=0.2), {}),
+               "ext_nointr": (lambda: synth.scene_extrinsics(4, 2, noise_px=0.2), dict(optimize_intrinsics=0)),
+               "bundle": (lambda: synth.scene_bundle(10, 2, noise_px=0.2), dict(optimize_intrinsics=1)),
+               "bundle_fixed": (lambda: synth.scene_bundle(10, 2, noise_px=0.2), dict(optimize_intrinsics=0, optimize_target_pose=0))}[kind]
+    a, b = mk(), mk()
+    o = options(**okw)
+    helpers.oracle_solve(oracle, a.flat, o)
+    cov0 = helpers.oracle_covariance(oracle, a.flat, o)
+    hm_solve(hostmath, b.flat, o)
+    d = b.flat.struct()
+    n = int(hostmath.hm_reproj_covariance_dim(C.byref(d)))
+    cov1 = np.zeros((n, n))
+    assert hostmath.hm_reproj_covariance(C.byref(d), C.byref(o), dptr(cov1)) == 0, hostmath.hm_last_error()
+    assert cov0 is not None and cov0.shape == cov1.shape
+    d0 = np.abs(np.diag(cov0))
+    assert np.array_equal(d0 == 0, np.diag(cov1) == 0)
+    nz = d0 > 0
+    assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-5
+
+
+def test_shard_views_partitions_the_problem():
+    sc = synth.scene_extrinsics(9, 3, noise_px=0.1)
+    parts = [synth.shard_views(sc.flat, r, 4) for r in range(4)]
+    assert sum(p.n_obs for p in parts) == sc.flat.n_obs
+    assert sum(p.n_views for p in parts) == sc.flat.n_views
+    assert [p.first_view_global for p in parts] == list(np.cumsum([0] + [p.n_views for p in parts[:-1]]))
+    for p in parts:
+        assert np.array_equal(p.intr, sc.flat.intr) and np.array_equal(p.cam_pose, sc.flat.cam_pose)
+        assert p.blk_view.max() < p.n_views

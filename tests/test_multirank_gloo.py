@@ -1,0 +1,109 @@
+"""CPU tier: the N > 1 path over gloo (world_size 2), no GPU.
+
+Views are sharded across ranks (synth.shard_views), shared parameters replicated, and the host LM
+driver issues its packed sum-all-reduces through the cba_allreduce_fn callback — the same driver,
+packing and callback contract libcalibba uses on GPUs (where the per-rank arithmetic runs in HIP
+kernels and the transport may be RCCL instead).  Here the per-rank arithmetic is the test-only CPU
+backend.  Checks: every rank ends with identical shared parameters, they match the 1-rank solve to
+1e-9 relative, and the gauge rule (global view 0 fixed) follows the shard that owns it.
+"""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(kind):
+    from calibration_amd import synth
+
+    if kind == "intr":
+        return synth.scene_intrinsics(11, spacing=0.08, noise_px=0.2)
+    if kind == "ext":
+        return synth.scene_extrinsics(7, 3, spacing=0.08, noise_px=0.2)
+    return synth.scene_bundle(13, 2, spacing=0.04, noise_px=0.2)
+
+
+def _worker(rank, world, port, kind, okw, outdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calibration_amd import capi, synth
+    from calibration_amd.capi import CbaSummary
+    from tests import helpers
+
+    hm = helpers.load_hostmath()
+    flat = synth.shard_views(_scene(kind).flat, rank, world)
+    calls = []
+
+    def allreduce(buf, count, _user):
+        arr = np.ctypeslib.as_array(buf, shape=(int(count),))
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t)  # in-place sum on the shared buffer
+        calls.append(int(count))
+        return 0
+
+    cb = capi.ALLREDUCE_FN(allreduce)
+    d = flat.struct()
+    s = CbaSummary()
+    o = helpers.options(epsilon=1e-12, **okw)
+    st = hm.hm_reproj_solve(C.byref(d), C.byref(o), cb, None, world, rank, C.byref(s))
+    assert st == 0, hm.hm_last_error()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), intr=flat.intr, cam=flat.cam_pose if flat.cam_pose is not None else np.zeros(0),
+             view=flat.view_pose if flat.view_pose is not None else np.zeros(0),
+             target=flat.target_pose if flat.target_pose is not None else np.zeros(0), first=flat.first_view_global,
+             iters=s.iterations, cost=s.final_cost, term=s.termination, ncalls=len(calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,okw", [("intr", {}), ("ext", {}), ("ext", dict(optimize_intrinsics=0)),
+                                       ("bundle", dict(optimize_intrinsics=1))])
+def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw):
+    import torch.multiprocessing as mp
+
+    from calibration_amd import capi
+    from calibration_amd.capi import CbaSummary
+    from tests import helpers
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, okw, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    # single-rank reference with the same driver
+    ref = _scene(kind).flat
+    d = ref.struct()
+    s = CbaSummary()
+    o = helpers.options(epsilon=1e-12, **okw)
+    assert hostmath.hm_reproj_solve(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, C.byref(s)) == 0
+    for r in res:
+        assert int(r["term"]) == s.termination
+        assert abs(int(r["iters"]) - s.iterations) <= 1
+        assert abs(float(r["cost"]) - s.final_cost) <= 1e-9 * max(1.0, s.final_cost)
+        assert int(r["ncalls"]) >= 2
+        assert helpers.rel_diff(ref.intr, r["intr"]) <= 1e-9
+        if ref.cam_pose is not None:
+            assert helpers.rel_diff(ref.cam_pose, r["cam"]) <= 1e-9
+        if ref.target_pose is not None:
+            assert helpers.rel_diff(ref.target_pose, r["target"]) <= 1e-9
+    # replicated blocks are bit-identical across ranks (same all-reduced sums, same host arithmetic)
+    assert np.array_equal(res[0]["intr"], res[1]["intr"]) and np.array_equal(res[0]["cam"], res[1]["cam"])
+    if ref.view_pose is not None:
+        views = np.concatenate([r["view"].reshape(-1, 7) for r in res])
+        assert helpers.rel_diff(ref.view_pose.reshape(-1, 7), views) <= 1e-9
+        assert int(res[0]["first"]) == 0 and int(res[1]["first"]) == res[0]["view"].reshape(-1, 7).shape[0]

@@ -1,0 +1,249 @@
+"""CPU tier: pins the oracle (oracle/) against
+  (1) the closed-form projection KATs of the reference (tests/unit/scheimpflug_test.cpp:11-51),
+  (2) golden residual/Jacobian vectors from independent derivations (tests/golden/gen_golden.py:
+      complex-step on a numpy forward model, 60-digit mpmath differences for AX=XB),
+  (3) the reference's ground-truth-recovery tests with the reference's own tolerances
+      (tests/unit/{intrinsics_optimize,bundle,scheimpflug_bundle,extrinsics,handeye}_test.cpp).
+Parity with Ceres' own iteration numerics is UNPINNED (no stored Ceres outputs exist, and Ceres is
+not buildable here): what is pinned is that the restated path reaches the same minimiser."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from calibration_amd import capi, optim, synth
+from calibration_amd.capi import CbaSummary, dptr
+from calibration_amd.geometry import pose_from_matrix, pose_to_matrix, rotation_angle
+from tests import helpers
+from tests.helpers import options
+from tests.planar_seed import estimate_planar_pose
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def _project(oracle, model, intr, P):
+    uv = np.zeros(2)
+    oracle.orc_project(model, dptr(np.ascontiguousarray(intr, dtype=float)), dptr(np.ascontiguousarray(P, dtype=float)), dptr(uv))
+    return uv
+
+
+# ---- (1) closed-form KATs ------------------------------------------------------------------------
+def test_scheimpflug_zero_tilt_matches_pinhole(oracle):
+    cam = np.array([800, 820, 320, 240, 0, 0, 0, 0, 0, 0], float)  # scheimpflug_test.cpp:11-28
+    P = np.array([0.2, -0.1, 1.0])
+    uv_s = _project(oracle, 1, np.concatenate([cam, [0.0, 0.0]]), P)
+    uv_p = _project(oracle, 0, cam, P)
+    assert abs(uv_s[0] - uv_p[0]) <= 1e-9 and abs(uv_s[1] - uv_p[1]) <= 1e-9
+    assert np.allclose(uv_p, [800 * 0.2 + 320, 820 * -0.1 + 240], atol=1e-12)
+
+
+def test_scheimpflug_principal_ray(oracle):
+    cam = np.array([600, 600, 400, 300, 0, 0, 0, 0, 0, 0], float)  # scheimpflug_test.cpp:30-51
+    taux, tauy = 0.1, -0.2
+    uv = _project(oracle, 1, np.concatenate([cam, [taux, tauy]]), np.array([0.0, 0.0, 1.0]))
+    m0 = np.array([-np.tan(tauy) / np.cos(taux), np.tan(taux)])
+    exp = _project(oracle, 0, cam, np.array([m0[0], m0[1], 1.0]))
+    assert abs(uv[0] - exp[0]) <= 1e-9 and abs(uv[1] - exp[1]) <= 1e-9
+
+
+def test_brown_conrady_hand_computed(oracle):
+    # distortion.h:99-115 by hand for one point: x=0.1, y=-0.2
+    k1, k2, k3, p1, p2 = -0.12, 0.02, 0.0005, -0.0007, 0.001
+    x, y = 0.1, -0.2
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    cam = np.array([900, 905, 640, 360, 0.5, k1, k2, k3, p1, p2])
+    uv = _project(oracle, 0, cam, np.array([x * 2.0, y * 2.0, 2.0]))
+    assert np.allclose(uv, [900 * xd + 0.5 * yd + 640, 905 * yd + 360], atol=1e-10)
+
+
+def test_numpy_forward_model_agrees_with_oracle(oracle):
+    rng = np.random.default_rng(0)
+    for model in (0, 1):
+        cam = synth.camera_gt(model)
+        for _ in range(50):
+            P = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(1.0, 3.0)])
+            assert np.allclose(_project(oracle, model, cam, P), synth.project(cam, P[None, :])[0], atol=1e-10)
+
+
+# ---- (2) golden vectors ----------------------------------------------------------------------------
+def _flat_from_golden(case, b):
+    chain, model = case["chain"], case["model"]
+    blk = case["blocks"][b]
+    view = np.concatenate([np.asarray(blk["XY"]), np.asarray(blk["uv"])], axis=1)
+    intr = np.asarray(case["intr"]).reshape(1, -1)
+    pA = np.asarray(blk["pA"])
+    if chain == capi.CHAIN_INTRINSIC:
+        return optim.FlatProblem(chain, model, [view], [0], [0], intr, None, pA.reshape(1, 7), None)
+    pB = np.asarray(blk["pB"]).reshape(1, 7)
+    if chain == capi.CHAIN_EXTRINSIC:
+        return optim.FlatProblem(chain, model, [view], [0], [0], intr, pB, pA.reshape(1, 7), None)
+    return optim.FlatProblem(chain, model, [view], [0], None, intr, pB, None, pA, np.asarray(blk["bTg"]).reshape(1, 12))
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_oracle_matches_complex_step_golden(oracle, idx):
+    case = _load("reproj_jacobians.json")[idx]
+    for b in range(len(case["blocks"])):
+        flat = _flat_from_golden(case, b)
+        r, J = helpers.oracle_eval(oracle, flat)
+        r0, J0 = np.asarray(case["blocks"][b]["r"]), np.asarray(case["blocks"][b]["J"])
+        assert np.abs(r - r0).max() <= 1e-9
+        assert (np.abs(J - J0) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+
+
+def test_oracle_axxb_matches_mpmath_golden(oracle):
+    for g in _load("axxb_pairs.json"):
+        p = np.asarray(g["pose"])
+        r, Jt = np.zeros(6), np.zeros(36)
+        q, t = np.ascontiguousarray(p[:4]), np.ascontiguousarray(p[4:])
+        oracle.orc_axxb_eval(dptr(q), dptr(t), dptr(np.asarray(g["RA"])), dptr(np.asarray(g["RB"])), dptr(np.asarray(g["tA"])),
+                             dptr(np.asarray(g["tB"])), dptr(r), dptr(None), dptr(None), dptr(Jt))
+        assert np.abs(r - np.asarray(g["r"])).max() <= 1e-12
+        assert np.abs(Jt.reshape(6, 6) - np.asarray(g["J"])).max() <= 1e-9
+
+
+# ---- (3) the reference's ground-truth-recovery tests through the oracle ---------------------------
+def _rot_err_deg(Ta, Tb):
+    return np.rad2deg(rotation_angle(np.asarray(Ta)[:3, :3].T @ np.asarray(Tb)[:3, :3]))
+
+
+def solve_kat_intrinsics(sc, solve):
+    views = [np.asarray(v) for v in sc["views"]]
+    cam0 = np.asarray(sc["cam_init"])
+    poses = [estimate_planar_pose(v, cam0[:5]) for v in views]
+    flat = optim.flatten_intrinsics(views, cam0, poses)
+    s = solve(flat, options(optimize_skew=int(sc["optimize_skew"])))
+    k, gt = flat.intr.reshape(-1), np.asarray(sc["cam_gt"])
+    assert s.success
+    assert np.abs(k[:4] - gt[:4]).max() <= sc["tol_K"]
+    assert abs(k[4] - gt[4]) <= sc["tol_skew"]
+    assert s.final_cost < sc["max_final_cost"]
+
+
+def solve_kat_bundle(sc, solve):
+    obs = [optim.BundleObservation(np.asarray(o["view"]), np.asarray(o["b_T_g"]), o["cam"]) for o in sc["obs"]]
+    flat = optim.flatten_bundle(obs, [np.asarray(c) for c in sc["cams_init"]], [np.asarray(T) for T in sc["g_T_c_init"]],
+                                np.asarray(sc["b_T_t_init"]))
+    so = sc["opts"]
+    o = options(optimize_intrinsics=int(so.get("optimize_intrinsics", False)), optimize_skew=int(so.get("optimize_skew", False)),
+                optimize_extrinsics=int(so.get("optimize_hand_eye", True)), optimize_target_pose=int(so.get("optimize_target_pose", True)),
+                huber_delta=so.get("huber_delta", 1.0))
+    s = solve(flat, o)
+    P = flat.intr.shape[-1]
+    for c, (Tgt, cgt) in enumerate(zip(sc["g_T_c_gt"], sc["cams_gt"])):
+        X = pose_to_matrix(flat.cam_pose.reshape(-1, 7)[c])
+        if "tol_rot_deg" in sc:
+            assert _rot_err_deg(X, Tgt) < sc["tol_rot_deg"]
+        if "tol_rot_rad" in sc:
+            assert np.deg2rad(_rot_err_deg(X, Tgt)) < sc["tol_rot_rad"]
+        assert np.linalg.norm(X[:3, 3] - np.asarray(Tgt)[:3, 3]) < sc["tol_trans"]
+        k = flat.intr.reshape(-1, P)[c]
+        if "tol_K" in sc:
+            assert np.abs(k[:4] - np.asarray(cgt)[:4]).max() <= sc["tol_K"]
+            assert abs(k[4] - cgt[4]) <= sc["tol_skew"]
+        if "tol_dist" in sc:
+            assert np.abs(k[5:10] - np.asarray(cgt)[5:10]).max() <= sc["tol_dist"]
+        if "tol_tau" in sc:
+            assert np.abs(k[10:12] - np.asarray(cgt)[10:12]).max() <= sc["tol_tau"]
+    if "tol_K" in sc:  # bundle_test.cpp:75-80: recovered base->target
+        B = pose_to_matrix(flat.target_pose)
+        assert _rot_err_deg(B, sc["b_T_t_gt"]) < sc["tol_rot_deg"]
+        assert np.linalg.norm(B[:3, 3] - np.asarray(sc["b_T_t_gt"])[:3, 3]) < sc["tol_trans"]
+    if "max_final_cost" in sc:
+        assert s.final_cost < sc["max_final_cost"]
+
+
+def _is_approx(a, b, prec):  # Eigen isApprox: |a-b| <= prec * min(|a|,|b|)
+    a, b = np.asarray(a), np.asarray(b)
+    return np.linalg.norm(a - b) <= prec * min(np.linalg.norm(a), np.linalg.norm(b))
+
+
+def solve_kat_extrinsics(sc, solve, covariance=None):
+    views = [[np.asarray(v) for v in mv] for mv in sc["views"]]
+    flat = optim.flatten_extrinsics(views, [np.asarray(c) for c in sc["cams_init"]], [np.asarray(T) for T in sc["c_T_r_init"]],
+                                    [np.asarray(T) for T in sc["r_T_t_init"]])
+    init_view0 = flat.view_pose.reshape(-1, 7)[0].copy()
+    o = options(optimize_intrinsics=int(sc["opts"].get("optimize_intrinsics", True)))
+    s = solve(flat, o)
+    if "max_final_cost" in sc:
+        assert s.final_cost < sc["max_final_cost"]
+    if "tol_pose" in sc:
+        c1 = pose_to_matrix(flat.cam_pose.reshape(-1, 7)[1])
+        g1 = np.asarray(sc["c_T_r_gt"][1])
+        assert _is_approx(c1[:3, 3], g1[:3, 3], sc["tol_pose"])
+        if not sc["opts"]:
+            assert _is_approx(pose_to_matrix(flat.view_pose.reshape(-1, 7)[0])[:3, 3], np.asarray(sc["r_T_t_gt"][0])[:3, 3], sc["tol_pose"])
+        else:
+            assert _is_approx(c1[:3, :3], g1[:3, :3], sc["tol_pose"])
+            for v, Tg in enumerate(sc["r_T_t_gt"]):
+                Tv = pose_to_matrix(flat.view_pose.reshape(-1, 7)[v])
+                assert _is_approx(Tv[:3, 3], np.asarray(Tg)[:3, 3], sc["tol_pose"])
+                assert _is_approx(Tv[:3, :3], np.asarray(Tg)[:3, :3], sc["tol_pose"])
+    if "tol_f" in sc:
+        assert abs(flat.intr.reshape(-1, 10)[0][0] - 100.0) <= sc["tol_f"] and abs(flat.intr.reshape(-1, 10)[0][1] - 100.0) <= sc["tol_f"]
+    if "gauge_tol" in sc:  # extrinsics_test.cpp:197-198
+        assert np.abs(flat.view_pose.reshape(-1, 7)[0][4:] - init_view0[4:]).max() <= sc["gauge_tol"]
+        assert s.final_cost > sc["min_final_cost"]
+    if sc.get("covariance_trace_positive") and covariance is not None:
+        cov = covariance(flat, o)
+        assert cov is not None and np.trace(cov) > 0.0
+
+
+def _oracle_solver(oracle):
+    return lambda flat, o: helpers.oracle_solve(oracle, flat, o)
+
+
+KAT = _load("kat_scenes.json")
+
+
+@pytest.mark.parametrize("name", [k for k, v in KAT.items() if v["kind"] == "intrinsics"])
+def test_reference_kat_intrinsics(oracle, name):
+    solve_kat_intrinsics(KAT[name], _oracle_solver(oracle))
+
+
+@pytest.mark.parametrize("name", [k for k, v in KAT.items() if v["kind"] == "bundle"])
+def test_reference_kat_bundle(oracle, name):
+    solve_kat_bundle(KAT[name], _oracle_solver(oracle))
+
+
+@pytest.mark.parametrize("name", [k for k, v in KAT.items() if v["kind"] == "extrinsics"])
+def test_reference_kat_extrinsics(oracle, name):
+    solve_kat_extrinsics(KAT[name], _oracle_solver(oracle), lambda flat, o: helpers.oracle_covariance(oracle, flat, o))
+
+
+def test_reference_kat_axxb(oracle):
+    sc = KAT["axxb_refine"]
+    bTg = [np.asarray(T) for T in sc["b_T_g"]]
+    cTt = [np.asarray(T) for T in sc["c_T_t"]]
+    pairs = np.ascontiguousarray(helpers.build_all_pairs(bTg, cTt, 0.5))
+    x = pose_from_matrix(np.asarray(sc["X_init"]))
+    e0r, e0t = _rot_err_deg(sc["X_init"], sc["X_gt"]), np.linalg.norm(np.asarray(sc["X_init"])[:3, 3] - np.asarray(sc["X_gt"])[:3, 3])
+    o = options(max_iterations=sc["opts"]["max_iterations"], huber_delta=sc["opts"]["huber_delta"])
+    s = CbaSummary()
+    cov = np.zeros((7, 7))
+    assert oracle.orc_axxb_solve(len(pairs), dptr(pairs), dptr(x), C.byref(o), C.byref(s), dptr(cov)) == 0
+    X = pose_to_matrix(x)
+    e1r, e1t = _rot_err_deg(X, sc["X_gt"]), np.linalg.norm(X[:3, 3] - np.asarray(sc["X_gt"])[:3, 3])
+    assert e1r < e0r and e1t < e0t
+    assert e1r < sc["tol_rot_deg"] and e1t < sc["tol_trans"]
+
+
+def test_oracle_input_validation(oracle):
+    """bundle_test.cpp:212-227: empty views -> std::invalid_argument."""
+    sc = synth.scene_bundle(4, 1)
+    f = sc.flat
+    f.blk_offset[1] = f.blk_offset[0]
+    d = f.struct()
+    s = CbaSummary()
+    o = options()
+    assert oracle.orc_reproj_solve(C.byref(d), C.byref(o), 1, C.byref(s)) == capi.CBA_ERR_INVALID_ARGUMENT
