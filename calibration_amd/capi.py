@@ -189,6 +189,15 @@ def load_library(path: Optional[str] = None):
     if _LIB is not None and path is None:
         return _LIB
     p = path or library_path()
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / librccl / libhsa-runtime64 (same SONAMEs as the
+    # system ROCm libraries libcalibba.so links).  If libcalibba is loaded first and torch later, glibc maps
+    # BOTH copies (torch asks for the unversioned file names) and the process ends up with two HIP runtimes.
+    # Importing torch first makes libcalibba bind to the copies torch already mapped: one HIP runtime, and
+    # the same RCCL that torch.distributed's "nccl" backend uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a host without PyTorch: the system ROCm libraries are used
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
