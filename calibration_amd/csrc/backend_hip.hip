@@ -498,8 +498,4 @@ void compute_covariance(Engine& e, const cba_options& o, double* cov) {
     drv.covariance(o, cov);
 }
 
-void handeye_solve(int, const double*, const double*, double*, const cba_options*, cba_summary*, double*, int) {
-    throw std::runtime_error("cba_optimize_handeye: AX=XB kernel not built yet");
-}
-
 }  // namespace cba

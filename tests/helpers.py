@@ -47,6 +47,11 @@ def load_hostmath():
     h.hm_reproj_covariance_dim.argtypes = [PP]
     h.hm_reproj_covariance_dim.restype = C.c_int64
     h.hm_reproj_covariance.argtypes = [PP, PO, c_double_p]
+    h.hm_handeye_last_error.restype = C.c_char_p
+    h.hm_axxb_eval.argtypes = [c_double_p] * 8
+    h.hm_axxb_eval.restype = None
+    h.hm_build_pairs.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p]
+    h.hm_handeye_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
     return h
 
 
@@ -168,3 +173,24 @@ def build_all_pairs(b_T_g, c_T_t, min_angle_deg=0.5, reject_axis_parallel=True, 
                     continue
             out.append(np.concatenate([A[:3, :3].reshape(-1), B[:3, :3].reshape(-1), A[:3, 3], B[:3, 3]]))
     return np.asarray(out)
+
+
+def handeye_scene(n_poses=18, seed=2024, noise_rot_deg=0.0, noise_trans=0.0):
+    """AX=XB scene per handeye_test.cpp:101-125 (numpy stream): returns (b_T_g, c_T_t, X_gt, X_init) as 4x4 lists."""
+    from calibration_amd.geometry import axis_angle_to_R, inv, make_pose
+    from tests.golden.gen_golden import RNG, sim_sequence
+
+    rng = RNG(seed)
+    X = make_pose([0.02, -0.01, 0.09], rng.rand_unit_axis(), np.deg2rad(10.0))
+    bTt = make_pose([0.25, 0.05, 0.55], rng.rand_unit_axis(), np.deg2rad(18.0))
+    seq = sim_sequence(n_poses, rng)
+    cTt = []
+    for T in seq:
+        M = inv(X) @ inv(T) @ bTt
+        if noise_rot_deg > 0 or noise_trans > 0:
+            M = make_pose(rng.gauss(noise_trans, 3), rng.rand_unit_axis(), np.deg2rad(abs(rng.gauss(noise_rot_deg)))) @ M
+        cTt.append(M)
+    X0 = X.copy()
+    X0[:3, :3] = axis_angle_to_R(rng.rand_unit_axis(), np.deg2rad(2.0)) @ X0[:3, :3]
+    X0[:3, 3] += [0.01, -0.005, 0.004]
+    return seq, cTt, X, X0

@@ -230,3 +230,46 @@ def test_mirror_api_end_to_end(gpu_lib):
                                     [np.asarray(T) for T in sc["c_T_r_init"]], [np.asarray(T) for T in sc["r_T_t_init"]],
                                     optim.ExtrinsicOptions(optimize_intrinsics=False))
     assert res.core.final_cost < 1e-6 and len(res.r_se3_t) == 3
+
+
+# ---- AX = XB on the GPU ------------------------------------------------------------------------------
+def test_reference_kat_axxb_on_gpu(gpu_lib):
+    from calibration_amd.geometry import rotation_angle
+
+    sc = kat.KAT["axxb_refine"]
+    X_gt, X0 = np.asarray(sc["X_gt"]), np.asarray(sc["X_init"])
+    res = optim.optimize_handeye([np.asarray(T) for T in sc["b_T_g"]], [np.asarray(T) for T in sc["c_T_t"]], X0,
+                                 optim.OptimOptions(optimizer=3, max_iterations=60, huber_delta=1.0))
+    e0r = np.rad2deg(rotation_angle(X0[:3, :3].T @ X_gt[:3, :3]))
+    e1r = np.rad2deg(rotation_angle(res.g_se3_c[:3, :3].T @ X_gt[:3, :3]))
+    e1t = np.linalg.norm(res.g_se3_c[:3, 3] - X_gt[:3, 3])
+    assert e1r < e0r and e1r < sc["tol_rot_deg"] and e1t < sc["tol_trans"]
+    assert res.core.covariance is not None and res.core.covariance.shape == (7, 7)
+
+
+@pytest.mark.parametrize("n_poses,noise", [(14, 0.0), (60, 0.3), (301, 0.3)])
+def test_handeye_gpu_matches_oracle(gpu_lib, oracle, n_poses, noise):
+    from calibration_amd.geometry import pose_from_matrix
+
+    bTg, cTt, X_gt, X0 = helpers.handeye_scene(n_poses, seed=11, noise_rot_deg=noise, noise_trans=0.002 if noise else 0.0)
+    pairs = np.ascontiguousarray(helpers.build_all_pairs(bTg, cTt, 0.5))
+    o = options(epsilon=1e-12)
+    xa = pose_from_matrix(X0)
+    sa, ca = capi.CbaSummary(), np.zeros((7, 7))
+    assert oracle.orc_axxb_solve(len(pairs), capi.dptr(pairs), capi.dptr(xa), C.byref(o), C.byref(sa), capi.dptr(ca)) == 0
+    pb = np.stack([pose_from_matrix(T) for T in bTg])
+    pc = np.stack([pose_from_matrix(T) for T in cTt])
+    xb = pose_from_matrix(X0)
+    sb, cb = capi.CbaSummary(), np.zeros((7, 7))
+    capi.check(gpu_lib, gpu_lib.cba_optimize_handeye(n_poses, capi.dptr(pb), capi.dptr(pc), capi.dptr(xb), C.byref(o), C.byref(sb), capi.dptr(cb)))
+    assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 1
+    assert f"{len(pairs)} pairs".encode() in sb.report
+    assert np.abs(xa - xb).max() <= 1e-9
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost) + 1e-18
+    assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
+
+
+def test_handeye_degenerate_is_runtime_error_on_gpu(gpu_lib):
+    with pytest.raises(capi.CbaError) as ei:
+        optim.optimize_handeye([np.eye(4)] * 5, [np.eye(4)] * 5, np.eye(4))
+    assert ei.value.status == capi.CBA_ERR_RUNTIME and "No valid motion pairs" in ei.value.message

@@ -239,3 +239,49 @@ def test_shard_views_partitions_the_problem():
     for p in parts:
         assert np.array_equal(p.intr, sc.flat.intr) and np.array_equal(p.cam_pose, sc.flat.cam_pose)
         assert p.blk_view.max() < p.n_views
+
+
+# ---- AX = XB (a4) ------------------------------------------------------------------------------------
+def test_axxb_device_math_matches_mpmath_golden(hostmath):
+    import json
+
+    for g in json.load(open(os.path.join(ROOT, "tests", "golden", "axxb_pairs.json"))):
+        p = np.asarray(g["pose"])
+        r, J = np.zeros(6), np.zeros(36)
+        hostmath.hm_axxb_eval(dptr(np.ascontiguousarray(p[:4])), dptr(np.ascontiguousarray(p[4:])), dptr(np.asarray(g["RA"])),
+                              dptr(np.asarray(g["RB"])), dptr(np.asarray(g["tA"])), dptr(np.asarray(g["tB"])), dptr(r), dptr(J))
+        assert np.abs(r - np.asarray(g["r"])).max() <= 1e-12
+        assert np.abs(J.reshape(6, 6) - np.asarray(g["J"])).max() <= 1e-9
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.3])
+def test_handeye_pairs_and_lm_match_oracle(oracle, hostmath, noise):
+    bTg, cTt, X_gt, X0 = helpers.handeye_scene(14, seed=11, noise_rot_deg=noise, noise_trans=0.002 if noise else 0.0)
+    pb = np.stack([pose_from_matrix(T) for T in bTg])
+    pc = np.stack([pose_from_matrix(T) for T in cTt])
+    n = len(pb)
+    ref_pairs = helpers.build_all_pairs(bTg, cTt, 0.5)  # numpy restatement of handeyedlt.cpp:51-81
+    cnt = hostmath.hm_build_pairs(n, dptr(pb), dptr(pc), dptr(None))
+    assert cnt == len(ref_pairs)
+    pairs = np.zeros((cnt, 24))
+    hostmath.hm_build_pairs(n, dptr(pb), dptr(pc), dptr(pairs))
+    assert np.abs(pairs - ref_pairs).max() <= 1e-12
+    o = options(epsilon=1e-12)
+    xa, xb = pose_from_matrix(X0), pose_from_matrix(X0)
+    sa, sb = CbaSummary(), CbaSummary()
+    ca, cb = np.zeros((7, 7)), np.zeros((7, 7))
+    assert oracle.orc_axxb_solve(cnt, dptr(pairs), dptr(xa), C.byref(o), C.byref(sa), dptr(ca)) == 0
+    assert hostmath.hm_handeye_solve(n, dptr(pb), dptr(pc), dptr(xb), C.byref(o), C.byref(sb), dptr(cb)) == 0
+    assert sa.termination == sb.termination and abs(sa.iterations - sb.iterations) <= 1
+    assert np.abs(xa - xb).max() <= 1e-9
+    assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
+
+
+def test_handeye_degenerate_motion_is_runtime_error(hostmath):
+    """handeye_test.cpp:61-68: identical poses -> no valid pairs -> std::runtime_error."""
+    p = np.tile(pose_from_matrix(np.eye(4)), (5, 1))
+    x = pose_from_matrix(np.eye(4))
+    s = CbaSummary()
+    o = options()
+    assert hostmath.hm_handeye_solve(5, dptr(p), dptr(p.copy()), dptr(x), C.byref(o), C.byref(s), dptr(None)) == capi.CBA_ERR_RUNTIME
+    assert b"No valid motion pairs" in hostmath.hm_handeye_last_error()
