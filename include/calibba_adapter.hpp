@@ -1,0 +1,220 @@
+// calibba_adapter.hpp — header-only C++ adapter that gives libcalibba.so the EXACT signatures of the
+// reference's refinement entry points, so `calib::pipeline` and the tests can link against it instead of
+// calib_estimation_optim.  It needs Eigen and the reference's own headers (calib/models/*,
+// calib/estimation/optim/*), therefore it is compiled in the reference's tree, not in this repository
+// (neither Eigen nor Ceres exist in the build image).  It only flattens AoS containers into the SoA
+// buffers of include/calibba.h and maps status codes back to the reference's exception types.
+//
+//   replaces                                               (reference file:line)
+//   calib::optimize_intrinsics<CameraT>                    src/estimation/optim/intrinsics.cpp:98-120
+//   calib::optimize_extrinsics<CameraT>                    src/estimation/optim/extrinsics.cpp:174-196
+//   calib::optimize_bundle<CameraT>                        src/estimation/optim/bundle.cpp:147-170
+//   calib::optimize_handeye                                src/estimation/optim/handeye.cpp:60-78
+#pragma once
+#include <Eigen/Geometry>
+#include <array>
+#include <stdexcept>
+#include <vector>
+
+#include "calib/estimation/optim/bundle.h"
+#include "calib/estimation/optim/extrinsics.h"
+#include "calib/estimation/optim/handeye.h"
+#include "calib/estimation/optim/intrinsics.h"
+#include "calib/models/scheimpflug.h"
+#include "calibba.h"
+
+namespace calibba_adapter {
+
+inline void check(cba_status st) {
+    if (st == CBA_OK) return;
+    if (st == CBA_ERR_INVALID_ARGUMENT) throw std::invalid_argument(cba_last_error());
+    throw std::runtime_error(cba_last_error());
+}
+
+template <class CameraT> struct ModelOf { static constexpr int value = CBA_CAMERA_PINHOLE_BC; };
+template <class Inner> struct ModelOf<calib::ScheimpflugCamera<Inner>> { static constexpr int value = CBA_CAMERA_SCHEIMPFLUG; };
+
+inline cba_options make_options(const calib::OptimOptions& core) {
+    cba_options o;
+    cba_options_default(&o);
+    o.optimizer = static_cast<int32_t>(core.optimizer);
+    o.huber_delta = core.huber_delta;
+    o.epsilon = core.epsilon;
+    o.max_iterations = core.max_iterations;
+    o.compute_covariance = core.compute_covariance;
+    o.verbose = core.verbose;
+    return o;
+}
+
+inline void fill_core(const cba_summary& s, const cba_options& o, const std::vector<double>& cov, Eigen::Index dim,
+                      calib::OptimResult& core) {
+    core.success = s.success != 0;
+    core.final_cost = s.final_cost;
+    core.report = s.report;
+    if (o.compute_covariance && dim > 0) {
+        // row-major symmetric -> Eigen (symmetric, so the storage order is immaterial); the engine zero-fills
+        // the matrix when the Jacobian is rank deficient, where the reference leaves it empty
+        Eigen::MatrixXd m = Eigen::Map<const Eigen::MatrixXd>(cov.data(), dim, dim);
+        if (m.diagonal().cwiseAbs().maxCoeff() > 0.0) core.covariance = std::move(m);
+    }
+}
+
+struct Soa {
+    std::vector<double> X, Y, u, v;
+    std::vector<int64_t> off{0};
+    std::vector<int32_t> cam, view;
+    std::vector<double> bTg;
+    void push(const calib::PlanarView& pv, int c, int vw) {
+        for (const auto& ob : pv) {
+            X.push_back(ob.object_xy.x()); Y.push_back(ob.object_xy.y());
+            u.push_back(ob.image_uv.x()); v.push_back(ob.image_uv.y());
+        }
+        off.push_back(static_cast<int64_t>(X.size()));
+        cam.push_back(c); view.push_back(vw);
+    }
+};
+
+inline void pose_in(const Eigen::Isometry3d& T, double* p7) { cba_pose_from_matrix(T.data(), p7); }
+inline Eigen::Isometry3d pose_out(const double* p7) {
+    Eigen::Isometry3d T;
+    cba_pose_to_matrix(p7, T.data());
+    return T;
+}
+
+template <calib::camera_model CameraT>
+auto optimize_intrinsics(const std::vector<calib::PlanarView>& views, const CameraT& init_camera,
+                         std::vector<Eigen::Isometry3d> init_c_se3_t, const calib::IntrinsicsOptimOptions& opts = {})
+    -> calib::IntrinsicsOptimizationResult<CameraT> {
+    using Traits = calib::CameraTraits<CameraT>;
+    std::array<double, Traits::param_count> intr{};
+    Traits::to_array(init_camera, intr);
+    Soa s;
+    for (size_t i = 0; i < views.size(); ++i) s.push(views[i], 0, static_cast<int>(i));
+    std::vector<double> poses(7 * init_c_se3_t.size());
+    for (size_t i = 0; i < init_c_se3_t.size(); ++i) pose_in(init_c_se3_t[i], &poses[7 * i]);
+    cba_options o = make_options(opts.core);
+    o.optimize_skew = opts.optimize_skew;
+    cba_summary sum{};
+    const Eigen::Index dim = static_cast<Eigen::Index>(Traits::param_count + 7 * views.size());
+    std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
+    check(cba_optimize_intrinsics(ModelOf<CameraT>::value, static_cast<int32_t>(views.size()), s.off.data(), s.X.data(),
+                                  s.Y.data(), s.u.data(), s.v.data(), intr.data(), poses.data(), &o, &sum,
+                                  cov.empty() ? nullptr : cov.data()));
+    calib::IntrinsicsOptimizationResult<CameraT> res;
+    res.camera = Traits::template from_array<double>(intr.data());
+    res.c_se3_t.resize(views.size());
+    for (size_t i = 0; i < views.size(); ++i) res.c_se3_t[i] = pose_out(&poses[7 * i]);
+    fill_core(sum, o, cov, dim, res.core);
+    return res;
+}
+
+template <calib::camera_model CameraT>
+auto optimize_extrinsics(const std::vector<calib::MulticamPlanarView>& views, const std::vector<CameraT>& init_cameras,
+                         const std::vector<Eigen::Isometry3d>& init_c_se3_r, const std::vector<Eigen::Isometry3d>& init_r_se3_t,
+                         const calib::ExtrinsicOptions& opts = {}) -> calib::ExtrinsicOptimizationResult<CameraT> {
+    using Traits = calib::CameraTraits<CameraT>;
+    constexpr size_t P = Traits::param_count;
+    const size_t C = init_cameras.size(), V = views.size();
+    if (init_c_se3_r.size() != C || init_r_se3_t.size() != V)  // extrinsics.cpp:162-172
+        throw std::invalid_argument("Incompatible pose vector sizes for joint optimization");
+    std::vector<double> intr(C * P), cams(7 * C), tgts(7 * V);
+    for (size_t c = 0; c < C; ++c) {
+        std::array<double, P> a{};
+        Traits::to_array(init_cameras[c], a);
+        std::copy(a.begin(), a.end(), intr.begin() + c * P);
+        pose_in(init_c_se3_r[c], &cams[7 * c]);
+    }
+    for (size_t v = 0; v < V; ++v) pose_in(init_r_se3_t[v], &tgts[7 * v]);
+    Soa s;
+    for (size_t v = 0; v < V; ++v)
+        for (size_t c = 0; c < C; ++c)
+            if (!views[v][c].empty()) s.push(views[v][c], static_cast<int>(c), static_cast<int>(v));  // extrinsics.cpp:94-96
+    cba_options o = make_options(opts.core);
+    o.optimize_intrinsics = opts.optimize_intrinsics;
+    o.optimize_skew = opts.optimize_skew;
+    o.optimize_extrinsics = opts.optimize_extrinsics;
+    cba_summary sum{};
+    const Eigen::Index dim = static_cast<Eigen::Index>(C * (P + 7) + 7 * V);
+    std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
+    check(cba_optimize_extrinsics(ModelOf<CameraT>::value, static_cast<int32_t>(C), static_cast<int32_t>(V),
+                                  static_cast<int32_t>(s.cam.size()), s.off.data(), s.view.data(), s.cam.data(), s.X.data(),
+                                  s.Y.data(), s.u.data(), s.v.data(), intr.data(), cams.data(), tgts.data(), &o, &sum,
+                                  cov.empty() ? nullptr : cov.data()));
+    calib::ExtrinsicOptimizationResult<CameraT> res;
+    res.cameras.resize(C); res.c_se3_r.resize(C); res.r_se3_t.resize(V);
+    for (size_t c = 0; c < C; ++c) {
+        res.cameras[c] = Traits::template from_array<double>(&intr[c * P]);
+        res.c_se3_r[c] = pose_out(&cams[7 * c]);
+    }
+    for (size_t v = 0; v < V; ++v) res.r_se3_t[v] = pose_out(&tgts[7 * v]);
+    fill_core(sum, o, cov, dim, res.core);
+    return res;
+}
+
+template <calib::camera_model CameraT>
+auto optimize_bundle(const std::vector<calib::BundleObservation>& observations, const std::vector<CameraT>& initial_cameras,
+                     const std::vector<Eigen::Isometry3d>& init_g_se3_c, const Eigen::Isometry3d& init_b_se3_t,
+                     const calib::BundleOptions& opts = {}) -> calib::BundleResult<CameraT> {
+    using Traits = calib::CameraTraits<CameraT>;
+    constexpr size_t P = Traits::param_count;
+    const size_t C = initial_cameras.size();
+    if (C == 0) throw std::invalid_argument("No camera intrinsics provided");    // bundle.cpp:139-141
+    if (observations.empty()) throw std::invalid_argument("No observations provided");  // bundle.cpp:142-144
+    std::vector<double> intr(C * P), g(7 * C), bt(7);
+    for (size_t c = 0; c < C; ++c) {
+        std::array<double, P> a{};
+        Traits::to_array(initial_cameras[c], a);
+        std::copy(a.begin(), a.end(), intr.begin() + c * P);
+        pose_in(init_g_se3_c[c], &g[7 * c]);
+    }
+    pose_in(init_b_se3_t, bt.data());
+    Soa s;
+    for (const auto& ob : observations) {
+        s.push(ob.view, static_cast<int>(ob.camera_index), 0);
+        const Eigen::Matrix3d R = ob.b_se3_g.linear();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) s.bTg.push_back(R(r, c));  // row-major rotation
+        for (int k = 0; k < 3; ++k) s.bTg.push_back(ob.b_se3_g.translation()(k));
+    }
+    cba_options o = make_options(opts.core);
+    o.optimize_intrinsics = opts.optimize_intrinsics;
+    o.optimize_skew = opts.optimize_skew;
+    o.optimize_extrinsics = opts.optimize_hand_eye;
+    o.optimize_target_pose = opts.optimize_target_pose;
+    cba_summary sum{};
+    const Eigen::Index dim = static_cast<Eigen::Index>(C * (P + 7) + 7);
+    std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
+    check(cba_optimize_bundle(ModelOf<CameraT>::value, static_cast<int32_t>(C), static_cast<int32_t>(observations.size()),
+                              s.off.data(), s.cam.data(), s.bTg.data(), s.X.data(), s.Y.data(), s.u.data(), s.v.data(),
+                              intr.data(), g.data(), bt.data(), &o, &sum, cov.empty() ? nullptr : cov.data()));
+    calib::BundleResult<CameraT> res;
+    res.cameras.resize(C); res.g_se3_c.resize(C);
+    for (size_t c = 0; c < C; ++c) {
+        res.cameras[c] = Traits::template from_array<double>(&intr[c * P]);
+        res.g_se3_c[c] = pose_out(&g[7 * c]);
+    }
+    res.b_se3_t = pose_out(bt.data());
+    fill_core(sum, o, cov, dim, res.core);
+    return res;
+}
+
+inline auto optimize_handeye(const std::vector<Eigen::Isometry3d>& base_se3_gripper,
+                             const std::vector<Eigen::Isometry3d>& camera_se3_target,
+                             const Eigen::Isometry3d& init_gripper_se3_ref, const calib::OptimOptions& options = {})
+    -> calib::HandeyeResult {
+    if (base_se3_gripper.size() < 2 || base_se3_gripper.size() != camera_se3_target.size())  // handeyedlt.cpp:56-58
+        throw std::runtime_error("Inconsistent hand-eye input sizes");
+    const size_t n = base_se3_gripper.size();
+    std::vector<double> bg(7 * n), ct(7 * n), x(7), cov(49);
+    for (size_t i = 0; i < n; ++i) { pose_in(base_se3_gripper[i], &bg[7 * i]); pose_in(camera_se3_target[i], &ct[7 * i]); }
+    pose_in(init_gripper_se3_ref, x.data());
+    cba_options o = make_options(options);
+    cba_summary sum{};
+    check(cba_optimize_handeye(static_cast<int32_t>(n), bg.data(), ct.data(), x.data(), &o, &sum, cov.data()));
+    calib::HandeyeResult res;
+    res.g_se3_c = pose_out(x.data());
+    fill_core(sum, o, cov, 7, res.core);
+    return res;
+}
+
+}  // namespace calibba_adapter
