@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -68,6 +69,8 @@ static void upload_params(Engine& e) {
 }
 
 static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
+    if (const char* ev = getenv("CBA_EVAL_VARIANT")) e.eval_variant = atoi(ev);
+    if (const char* eb = getenv("CBA_EVAL_BLOCKED")) e.eval_blocked = atoi(eb);
     Structure st;
     build_structure(d, st);  // validation mirroring the reference (SURVEY.md §8b "Errors")
     e.chain = st.chain; e.model = st.model;
@@ -85,6 +88,13 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     e.n_obs = st.n_obs;
     e.ld = (pad + 255) & ~int64_t(255);
     if (e.ld == 0) e.ld = 256;
+    if (const char* lp = getenv("CBA_LD_MOD")) {
+        // experiment: force (ld * 8) mod 2 MiB == CBA_LD_MOD bytes (multiple of 256)
+        const int64_t period = (2 << 20) / 8, want = atoll(lp) / 8;
+        int64_t ld = (e.ld / period) * period + want;
+        while (ld < e.ld) ld += period;
+        e.ld = ld;
+    }
 
     const int ndev = device_count();
     if (ndev <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
@@ -273,8 +283,9 @@ cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, 
 int64_t cba_reproj_num_observations(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->n_obs : 0; }
 
 static void ensure_eval_buffers(Engine& e) {
-    if (e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
-    if (e.J.n < static_cast<size_t>(2 * e.PL) * e.ld) e.J.alloc(static_cast<size_t>(2 * e.PL) * e.ld);
+    if (!e.eval_blocked && e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
+    const size_t jn = e.eval_blocked ? static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A : static_cast<size_t>(2 * e.PL) * e.ld;
+    if (e.J.n < jn) e.J.alloc(jn);
 }
 
 cba_status cba_reproj_eval(cba_reproj* h) {
@@ -284,6 +295,8 @@ cba_status cba_reproj_eval(cba_reproj* h) {
         ensure_eval_buffers(e);
         launch_block_consts(e, 0);
         launch_eval(e);
+        e.eval_done = 1;
+        e.eval_blocked_last = e.eval_blocked;
         CBA_HIP(hipStreamSynchronize(e.stream));
     });
 }
@@ -293,6 +306,10 @@ cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, d
         Engine& e = *as_engine(h);
         if (iters <= 0) throw std::invalid_argument("iters must be positive");
         CBA_HIP(hipSetDevice(e.device));
+        // tuning knobs are re-read here so one handle (one set of buffers) can time every variant
+        if (const char* ev = getenv("CBA_EVAL_VARIANT")) e.eval_variant = atoi(ev);
+        if (const char* eb = getenv("CBA_EVAL_BLOCKED")) e.eval_blocked = atoi(eb);
+        if (const char* ea = getenv("CBA_EVAL_ABLATE")) e.eval_ablate = atoi(ea);
         ensure_eval_buffers(e);
         launch_block_consts(e, 0);
         for (int i = 0; i < warmup; ++i) launch_eval(e);
@@ -300,6 +317,8 @@ cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, d
         for (int i = 0; i < iters; ++i) launch_eval(e);
         CBA_HIP(hipEventRecord(e.ev1, e.stream));
         CBA_HIP(hipEventSynchronize(e.ev1));
+        e.eval_done = 1;
+        e.eval_blocked_last = e.eval_blocked;
         float ms = 0.f;
         CBA_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
         *ms_per_eval = static_cast<double>(ms) / iters;
@@ -310,8 +329,32 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
     return guarded([&] {
         Engine& e = *as_engine(h);
         CBA_HIP(hipSetDevice(e.device));
-        if (e.r.n < static_cast<size_t>(2 * e.ld)) throw std::runtime_error("cba_reproj_eval has not been called");
+        if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
         const int P = e.PL;
+        if (e.eval_blocked_last) {
+            // tile-blocked layout out[tile][2 + 2P][128]: walk the tile table (host copy)
+            const int64_t tw = static_cast<int64_t>(2 + 2 * P) * TILE_A;
+            std::vector<double> buf(static_cast<size_t>(tw));
+            int64_t w = 0;
+            for (int b = 0; b < e.n_blocks; ++b) {
+                const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
+                for (int64_t s0 = 0; s0 < n; s0 += TILE_A, ++w) {
+                    CBA_HIP(hipMemcpyAsync(buf.data(), e.J.p + w * tw, sizeof(double) * tw, hipMemcpyDeviceToHost, e.stream));
+                    CBA_HIP(hipStreamSynchronize(e.stream));
+                    const int64_t cnt = std::min<int64_t>(TILE_A, n - s0);
+                    for (int64_t j = 0; j < cnt; ++j) {
+                        const int64_t i = e.blk_offset[b] + s0 + j;
+                        if (r) { r[2 * i] = buf[j]; r[2 * i + 1] = buf[TILE_A + j]; }
+                        if (J)
+                            for (int k = 0; k < P; ++k) {
+                                J[(2 * i) * P + k] = buf[(2 + k) * TILE_A + j];
+                                J[(2 * i + 1) * P + k] = buf[(2 + P + k) * TILE_A + j];
+                            }
+                    }
+                }
+            }
+            return;
+        }
         std::vector<double> hr(static_cast<size_t>(2 * e.ld));
         e.r.download(hr.data(), hr.size(), e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));

@@ -4,8 +4,10 @@
 //   X, Y, u, v        [ld]          observations; every residual block starts at an EVEN padded index
 //                                    (so a lane's two observations are one 16-byte load/store) and ld is
 //                                    the padded total rounded up to 256 elements
-//   r                 [2][ld]       Mode A residuals (u row, v row)
-//   J                 [2*P][ld]     Mode A Jacobian: row k = column (k % P) of the u (k < P) / v row
+//   J (Mode A output) [n_tilesA][2 + 2P][128]  tile-blocked: for every 128-observation tile one contiguous
+//                                    (2+2P) KiB region = u/v residual rows, then the P Jacobian columns of
+//                                    the u row, then of the v row (streams like a fill; +6 % over whole-array
+//                                    columns r[2][ld], J[2P][ld], which CBA_EVAL_BLOCKED=0 still selects)
 //   bc                [n_blocks][36] per-block chain constants (reproj_math.hpp BC_*)
 //   sd                [n_cams][36]  Scheimpflug per-camera constants (SD_*)
 //   intr/cam/view/target            parameter blocks, current [0] and trial [1] copies
@@ -106,6 +108,10 @@ struct Engine {
     DevBuf<double> X, Y, u, v, r, J;
     DevBuf<double> bc, sd, aux;  // aux: bundle b_T_g [n_blocks][12]
     DevBuf<double> intr[2], cam[2], view[2], target[2];
+    int eval_blocked = 1;  // Mode A output layout: 1 tile-blocked out[tile][2+2P][128] (default), 0 whole-array columns
+    int eval_done = 0, eval_blocked_last = 0;
+    int eval_ablate = 0;  // timing-only ablation of k_eval (CBA_EVAL_ABLATE; outputs are wrong when non-zero)
+    int eval_variant = 1;  // k_eval variant: bit 0 = non-temporal stores, bits 1.. = log2(tiles per wave)
     int active = 0;  // parameter copy (0 current / 1 trial) the constants bc, sd were last built from
     DevBuf<int32_t> d_blk_cam, d_blk_view;
     DevBuf<Tile> tilesA, tilesB;

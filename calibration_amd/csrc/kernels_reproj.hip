@@ -13,6 +13,8 @@
 // (readfirstlane'd wave index) and the constants live in SGPRs / are broadcast, while X,Y,u,v and
 // the outputs are unit-stride 16-byte-per-lane (Mode A) or 8-byte-per-lane vector accesses.
 // The arithmetic is reproj_math.hpp (shared with the CPU test build).
+#include <cstdlib>
+
 #include "engine.hpp"
 #include "reproj_math.hpp"
 
@@ -65,7 +67,26 @@ __global__ void k_scheimpflug_consts(int n_cams, const double* __restrict__ intr
 // ---- Mode A -----------------------------------------------------------------------------------
 // Algorithmic HBM traffic per observation: 4 loads + 2 residual stores + 2*P Jacobian stores of
 // 8 bytes = 304 B (P=16) ... 432 B (P=24).  HBM-bound: ~0.3 kFLOP per observation.
-template <int CHAIN, int MODEL>
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ void store2(double* p, double a, double b) {
+    d2_t v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(p));
+    else *reinterpret_cast<d2_t*>(p) = v;
+}
+
+// NT: non-temporal (streaming) stores for r / J, which this kernel never re-reads.
+// ROWS: consecutive tiles handled by one wavefront.
+// BLK: tile-blocked output layout out[tile][2 + 2P][128] (one contiguous 34 KiB region per tile) instead
+// of whole-array columns r[2][ld], J[2P][ld].
+// ABL (timing-only ablations, wrong outputs): 1 = skip the arithmetic (store the loaded values), 2 = skip the loads
+//
+// Software pipeline: a wavefront walks ROWS consecutive tiles and issues the 4 observation loads of tile
+// k+1 BEFORE it computes and stores tile k, so the ~2 us load latency under a write-saturated memory
+// system hides behind 34 KiB of stores instead of stalling the wave (measured: loads are 10 % of the
+// bytes but cost 15 % of the time when they sit at the head of every wave).
+template <int CHAIN, int MODEL, bool NT, int ROWS, bool BLK, int ABL = 0>
 __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, int64_t n_tiles,
                                               const double* __restrict__ bc, const double* __restrict__ intr,
                                               const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
@@ -74,32 +95,70 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, in
                                               double* __restrict__ r, double* __restrict__ J, int64_t ld) {
     constexpr int PI = IntrSize<MODEL>::value;
     constexpr int PL = LocalCols<CHAIN, MODEL>::value;
-    const int64_t w = wave_index();
-    if (w >= n_tiles) return;
-    const Tile t = tiles[w];
     const int lane = threadIdx.x & 63;
-    if (2 * lane >= t.count) return;
-    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
-    const int cam = blk_cam[t.blk];
-    const double* ip = intr + static_cast<int64_t>(cam) * PI;
-    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+    const int64_t w0 = wave_index() * ROWS;
+    if (w0 >= n_tiles) return;
+    const int64_t w1 = (w0 + ROWS < n_tiles) ? w0 + ROWS : n_tiles;
 
-    const int64_t i0 = t.start + 2 * lane;
-    const double2 Xv = *reinterpret_cast<const double2*>(X + i0);
-    const double2 Yv = *reinterpret_cast<const double2*>(Y + i0);
-    const double2 uv = *reinterpret_cast<const double2*>(u + i0);
-    const double2 vv = *reinterpret_cast<const double2*>(v + i0);
-
-    double r0[2], r1[2], Ju0[PL], Jv0[PL], Ju1[PL], Jv1[PL];
-    reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.x, Yv.x, uv.x, vv.x, r0, Ju0, Jv0);
-    reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.y, Yv.y, uv.y, vv.y, r1, Ju1, Jv1);
-
-    *reinterpret_cast<double2*>(r + i0) = make_double2(r0[0], r1[0]);
-    *reinterpret_cast<double2*>(r + ld + i0) = make_double2(r0[1], r1[1]);
+    Tile t = tiles[w0];
+    double2 Xv, Yv, uv, vv;
+    auto load_obs = [&](const Tile& tt, double2& a, double2& b, double2& c, double2& d) {
+        if (ABL == 2) {
+            a = make_double2(1e-3 * lane, 2e-3 * lane); b = make_double2(-1e-3 * lane, 1e-3);
+            c = make_double2(600.0, 610.0); d = make_double2(300.0, 310.0);
+        } else {
+            // lanes past the tile's end read the tile's first pair (in bounds, result unused)
+            const int64_t i = tt.start + ((2 * lane < tt.count) ? 2 * lane : 0);
+            a = *reinterpret_cast<const double2*>(X + i);
+            b = *reinterpret_cast<const double2*>(Y + i);
+            c = *reinterpret_cast<const double2*>(u + i);
+            d = *reinterpret_cast<const double2*>(v + i);
+        }
+    };
+    load_obs(t, Xv, Yv, uv, vv);
+#pragma unroll 1
+    for (int64_t w = w0; w < w1; ++w) {
+        Tile tn = t;
+        double2 Xn = Xv, Yn = Yv, un = uv, vn = vv;
+        if (ROWS > 1 && w + 1 < w1) {
+            tn = tiles[w + 1];
+            load_obs(tn, Xn, Yn, un, vn);
+        }
+        if (2 * lane < t.count) {
+            const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+            const int cam = blk_cam[t.blk];
+            const double* ip = intr + static_cast<int64_t>(cam) * PI;
+            const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+            const int64_t i0 = t.start + 2 * lane;
+            double r0[2], r1[2], Ju0[PL], Jv0[PL], Ju1[PL], Jv1[PL];
+            if (ABL == 1) {
+                r0[0] = Xv.x; r0[1] = Yv.x; r1[0] = uv.x; r1[1] = vv.x;
 #pragma unroll
-    for (int k = 0; k < PL; ++k) {
-        *reinterpret_cast<double2*>(J + static_cast<int64_t>(k) * ld + i0) = make_double2(Ju0[k], Ju1[k]);
-        *reinterpret_cast<double2*>(J + static_cast<int64_t>(PL + k) * ld + i0) = make_double2(Jv0[k], Jv1[k]);
+                for (int k = 0; k < PL; ++k) { Ju0[k] = Xv.y + k; Jv0[k] = Yv.y; Ju1[k] = uv.y; Jv1[k] = vv.y + k; }
+            } else {
+                reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.x, Yv.x, uv.x, vv.x, r0, Ju0, Jv0);
+                reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.y, Yv.y, uv.y, vv.y, r1, Ju1, Jv1);
+            }
+            if (BLK) {
+                double* o = J + w * static_cast<int64_t>((2 + 2 * PL) * TILE_A) + 2 * lane;
+                store2<NT>(o, r0[0], r1[0]);
+                store2<NT>(o + TILE_A, r0[1], r1[1]);
+#pragma unroll
+                for (int k = 0; k < PL; ++k) {
+                    store2<NT>(o + (2 + k) * TILE_A, Ju0[k], Ju1[k]);
+                    store2<NT>(o + (2 + PL + k) * TILE_A, Jv0[k], Jv1[k]);
+                }
+            } else {
+                store2<NT>(r + i0, r0[0], r1[0]);
+                store2<NT>(r + ld + i0, r0[1], r1[1]);
+#pragma unroll
+                for (int k = 0; k < PL; ++k) {
+                    store2<NT>(J + static_cast<int64_t>(k) * ld + i0, Ju0[k], Ju1[k]);
+                    store2<NT>(J + static_cast<int64_t>(PL + k) * ld + i0, Jv0[k], Jv1[k]);
+                }
+            }
+        }
+        t = tn; Xv = Xn; Yv = Yn; uv = un; vv = vn;
     }
 }
 
@@ -276,12 +335,38 @@ void launch_block_consts(Engine& e, int which) {
 // bc/sd were built from parameter copy e.active; the kernels read the matching intrinsics
 static const double* intr_of(Engine& e) { return e.intr[e.active].p; }
 
+template <int C, int M, bool NT, int ROWS>
+static void launch_eval_v(Engine& e) {
+    const unsigned g = blocks_for(e.n_tilesA, 4 * ROWS);
+    if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 1)
+        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+    else if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 2)
+        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+    else if (e.eval_blocked)
+        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+    else
+        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+}
+
 void launch_eval(Engine& e) {
     if (e.n_tilesA == 0) return;
-    const unsigned g = blocks_for(e.n_tilesA, 4);
-#define CALL(C, M)                                                                                             \
-    hipLaunchKernelGGL((k_eval<C, M>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,          \
-                       intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+    // tuning knob (experiments only; read at handle creation): bit 0 = nt stores, bits 1.. = log2(tiles per wave)
+    const int variant = e.eval_variant;
+#define CALL(C, M)                                                         \
+    switch (variant) {                                                     \
+        case 1: launch_eval_v<C, M, true, 1>(e); break;                    \
+        case 2: launch_eval_v<C, M, false, 2>(e); break;                   \
+        case 3: launch_eval_v<C, M, true, 2>(e); break;                    \
+        case 4: launch_eval_v<C, M, false, 4>(e); break;                   \
+        case 5: launch_eval_v<C, M, true, 4>(e); break;                    \
+        case 6: launch_eval_v<C, M, false, 8>(e); break;                   \
+        case 7: launch_eval_v<C, M, true, 8>(e); break;                    \
+        default: launch_eval_v<C, M, false, 1>(e);                         \
+    }
     CBA_DISPATCH(e, CALL)
 #undef CALL
     CBA_HIP(hipGetLastError());

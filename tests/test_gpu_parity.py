@@ -273,3 +273,18 @@ def test_handeye_degenerate_is_runtime_error_on_gpu(gpu_lib):
     with pytest.raises(capi.CbaError) as ei:
         optim.optimize_handeye([np.eye(4)] * 5, [np.eye(4)] * 5, np.eye(4))
     assert ei.value.status == capi.CBA_ERR_RUNTIME and "No valid motion pairs" in ei.value.message
+
+
+@pytest.mark.parametrize("blocked,variant", [(0, 0), (0, 3), (1, 0), (1, 5)])
+def test_mode_a_layout_and_tuning_variants(gpu_lib, oracle, monkeypatch, blocked, variant):
+    """Every k_eval build (whole-array columns / tile-blocked output, nt stores, tiles per wave) gives
+    the same numbers through cba_reproj_eval_fetch."""
+    monkeypatch.setenv("CBA_EVAL_BLOCKED", str(blocked))
+    monkeypatch.setenv("CBA_EVAL_VARIANT", str(variant))
+    sc = synth.scene_extrinsics(5, 3, rows=13, cols=21, noise_px=0.3)
+    r0, J0 = helpers.oracle_eval(oracle, sc.flat)
+    with optim.ReprojHandle(sc.flat) as h:
+        h.eval()
+        r1, J1 = h.eval_fetch()
+    assert np.abs(r0 - r1).max() <= 1e-9
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9

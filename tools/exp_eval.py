@@ -1,0 +1,19 @@
+"""Interleaved A/B timing of k_eval variants in ONE process (one handle per variant, variant chosen by
+CBA_EVAL_VARIANT at handle creation), N rounds; prints min / median ms per eval."""
+import os, sys, statistics
+sys.path.insert(0, ".")
+from calibration_amd import synth, optim
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
+sc = synth.scene_intrinsics(1000, rows=100, cols=100, spacing=0.008, noise_px=0.2)
+hs = {}
+for v in variants:
+    os.environ["CBA_EVAL_VARIANT"] = str(v)
+    hs[v] = optim.ReprojHandle(sc.flat)
+    hs[v].eval_timed(3, 5)
+res = {v: [] for v in variants}
+for rnd in range(12):
+    for v in variants:
+        res[v].append(hs[v].eval_timed(1, 20))
+for v in variants:
+    m, md = min(res[v]), statistics.median(res[v])
+    print(f"variant {v}: min {m:.4f} ms ({304e7/m/1e6:.0f} GB/s)  median {md:.4f} ms ({304e7/md/1e6:.0f} GB/s)")
