@@ -7,8 +7,7 @@
 //   k_schur_view     per private view: damped H_pp = L L^T, y = L^-1 g_p, Z_b = L^-1 E_b
 //   k_schur_syrk     S_schur = sum_v Z_v^T Z_v, 64x64 output tiles, 4x4 register micro-tiles
 //   k_schur_gvec     g_schur = sum_v Z_v^T y_v
-//   k_backsub        delta_p, trial poses, step norms
-//   k_model          per-block model-cost terms
+//   k_backsub        delta_p, trial poses, step norms and the views' share of the model-cost terms
 // All reductions are two-stage with a fixed summation order (no atomics on fp64), so runs are
 // bitwise reproducible and 1/2/4/8-rank runs differ only by the all-reduce's own rounding.
 #include <rccl/rccl.h>
@@ -21,8 +20,8 @@
 
 namespace cba {
 
-constexpr int VCHUNK = 32;   // views per syrk / gvec workgroup
-constexpr int CCHUNK = 128;  // blocks per camera-sum chunk
+constexpr int VCHUNK = 8;    // views per syrk / gvec workgroup
+constexpr int CCHUNK = 16;   // blocks per camera-sum chunk
 
 __global__ void k_weights(int n_blocks, int NACC, int s_idx, const double* __restrict__ blk_acc, double huber_delta,
                           double* __restrict__ blk_w, double* __restrict__ blk_s) {
@@ -185,30 +184,17 @@ __global__ void k_schur_gvec(SchurDims d, int n_views, int nsh, const int32_t* _
 __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
                           const int32_t* __restrict__ blk_cam, const double* __restrict__ blk_Z,
                           const double* __restrict__ delta_sh, const int32_t* __restrict__ fixed, const double* __restrict__ L,
-                          const double* __restrict__ y, const double* __restrict__ x, double* __restrict__ delta_p,
-                          double* __restrict__ xt, double* __restrict__ stats /*[n_views][2]*/) {
+                          const double* __restrict__ y, const double* __restrict__ D, const double* __restrict__ gp,
+                          const double* __restrict__ x, double* __restrict__ delta_p, double* __restrict__ xt,
+                          double* __restrict__ stats /*[n_views][4]*/) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
-    double s2, x2;
+    double o4[4];
     backsub_view_body(d, nb, link_blk + link_off[v], blk_cam, blk_Z, delta_sh, fixed[v] != 0, L + 36 * static_cast<int64_t>(v),
-                      y + 6 * static_cast<int64_t>(v), x + 7 * static_cast<int64_t>(v), delta_p + 6 * static_cast<int64_t>(v),
-                      xt + 7 * static_cast<int64_t>(v), &s2, &x2);
-    stats[2 * static_cast<int64_t>(v)] = s2;
-    stats[2 * static_cast<int64_t>(v) + 1] = x2;
-}
-
-__global__ void k_model(SchurDims d, int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
-                        const double* __restrict__ blk_acc, const double* __restrict__ blk_w,
-                        const double* __restrict__ delta_p, const double* __restrict__ delta_sh,
-                        double* __restrict__ out /*[n_blocks][2]*/) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    double gd, dHd;
-    const double* dp = d.chain == CH_BUNDLE ? nullptr : delta_p + 6 * static_cast<int64_t>(blk_view[b]);
-    model_block_body(d, blk_cam[b], blk_acc + static_cast<int64_t>(b) * d.NACC, blk_w[b], dp, delta_sh, &gd, &dHd);
-    out[2 * static_cast<int64_t>(b)] = gd;
-    out[2 * static_cast<int64_t>(b) + 1] = dHd;
+                      y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v), gp + 6 * static_cast<int64_t>(v),
+                      x + 7 * static_cast<int64_t>(v), delta_p + 6 * static_cast<int64_t>(v), xt + 7 * static_cast<int64_t>(v), o4);
+    for (int k = 0; k < 4; ++k) stats[4 * static_cast<int64_t>(v) + k] = o4[k];
 }
 
 static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(std::max<int64_t>(1, (n + per - 1) / per)); }
@@ -221,8 +207,9 @@ struct HipLMState {
     DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
     DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
     DevBuf<int32_t> link_blk;
-    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, blk_model, syrk_partial, syrk_out, gvec_partial, gvec_out,
-        small_out;
+    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
+    DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
+    std::vector<double> schur_host;
 };
 
 struct HipBackend final : Backend {
@@ -278,23 +265,22 @@ struct HipBackend final : Backend {
                            st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, 256)), dim3(256), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
-                           st.syrk_partial.p, st.syrk_out.p);
+                           st.syrk_partial.p, st.schur_pack.p);
         hipLaunchKernelGGL(k_schur_gvec, dim3(st.n_vchunks), dim3(128), 0, e.stream, st.dims, s.n_views, n, st.view_cam_blk.p,
                            e.blk_Z.p, e.view_y.p, st.gvec_partial.p);
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, 128)), dim3(128), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
-                           static_cast<int64_t>(n), st.gvec_partial.p, st.gvec_out.p);
+                           static_cast<int64_t>(n), st.gvec_partial.p, st.schur_pack.p + sw);
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
-                           st.small_out.p);
+                           st.schur_pack.p + sw + n);
         CBA_HIP(hipGetLastError());
-        std::vector<double> tiles(static_cast<size_t>(sw));
-        st.syrk_out.download(tiles.data(), tiles.size(), e.stream);
-        st.gvec_out.download(g.data(), g.size(), e.stream);
-        double gm = 0.0;
+        std::vector<double>& tiles = st.schur_host;
+        tiles.resize(static_cast<size_t>(sw) + n + 1);
+        st.schur_pack.download(tiles.data(), tiles.size(), e.stream);
         int32_t nf = 0;
-        st.small_out.download(&gm, 1, e.stream);
         st.nfail.download(&nf, 1, e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
-        *gmax_priv = gm;
+        for (int i = 0; i < n; ++i) g[i] = tiles[static_cast<size_t>(sw) + i];
+        *gmax_priv = tiles[static_cast<size_t>(sw) + n];
         *nfail = nf;
         int pair = 0;
         for (int ti = 0; ti < st.n_tiles; ++ti)
@@ -320,14 +306,10 @@ struct HipBackend final : Backend {
         if (s.n_views > 0) {
             hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
-                               e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
-            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 2, st.view_stats.p,
+                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
                                static_cast<const double*>(nullptr), st.small_out.p + 8);
         }
-        hipLaunchKernelGGL(k_model, dim3(nblk(s.n_blocks, 128)), dim3(128), 0, e.stream, st.dims, s.n_blocks, e.d_blk_cam.p,
-                           e.d_blk_view.p, e.blk_acc.p, e.blk_w.p, st.view_delta.p, e.delta_sh.p, st.blk_model.p);
-        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_blocks, 2, st.blk_model.p,
-                           static_cast<const double*>(nullptr), st.small_out.p + 16);
         // cost at the trial point (Mode R); blk_s / blk_w of the ACCEPTED point stay in blk_acc / blk_w
         launch_block_consts(e, 1);
         launch_resid_trial(e, huber);
@@ -339,8 +321,8 @@ struct HipBackend final : Backend {
         CBA_HIP(hipStreamSynchronize(e.stream));
         out->step2 = s.n_views > 0 ? h[8] : 0.0;
         out->xnorm2 = s.n_views > 0 ? h[9] : 0.0;
-        out->gd = h[16];
-        out->dHd = h[17];
+        out->gd = s.n_views > 0 ? h[10] : 0.0;
+        out->dHd = s.n_views > 0 ? h[11] : 0.0;
         out->cost = c2[0];
     }
     void launch_resid_trial(Engine& eng, double huber) {
@@ -404,12 +386,10 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d) {
     st->view_gmax.alloc(nv);
     st->view_delta.alloc(nv * 6);
     st->view_delta.zero(e.stream);
-    st->view_stats.alloc(nv * 2);
-    st->blk_model.alloc(static_cast<size_t>(std::max(1, s.n_blocks)) * 2);
+    st->view_stats.alloc(nv * 4);
     st->syrk_partial.alloc(static_cast<size_t>(st->n_vchunks) * st->n_pairs * 4096);
-    st->syrk_out.alloc(static_cast<size_t>(st->n_pairs) * 4096);
+    st->schur_pack.alloc(static_cast<size_t>(st->n_pairs) * 4096 + s.nsh + 8);
     st->gvec_partial.alloc(static_cast<size_t>(st->n_vchunks) * s.nsh);
-    st->gvec_out.alloc(s.nsh);
     st->small_out.alloc(32);
     st->small_out.zero(e.stream);
     e.blk_w.alloc(std::max(1, s.n_blocks));

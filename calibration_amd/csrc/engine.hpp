@@ -75,7 +75,7 @@ struct Tile {       // 16 bytes, read with one scalar load per wave
 };
 
 constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
-constexpr int OPL_B = 8;     // Mode B/R: observations per lane per tile
+constexpr int OPL_B = 16;    // Mode B/R: observations per lane per tile
 constexpr int TILE_B = 64 * OPL_B;
 
 struct ViewLink {  // CSR of residual blocks per private view (Schur elimination)

@@ -8,6 +8,7 @@
 // sum over workgroups (no atomics; bitwise reproducible).  Compute-bound: ~1.2 kFLOP per pair.
 #include "engine.hpp"
 #include "handeye_core.hpp"
+#include "wave_reduce.hpp"
 
 namespace cba {
 
@@ -33,10 +34,8 @@ __global__ __launch_bounds__(256) void k_axxb(int n, const double* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < AXXB_NACC; ++e) {
-        double v = acc[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) sh[wave][e] = v;
+        const double v = wave_sum63(acc[e]);
+        if (lane == 63) sh[wave][e] = v;
     }
     __syncthreads();
     if (threadIdx.x < AXXB_NACC)

@@ -17,6 +17,7 @@
 
 #include "engine.hpp"
 #include "reproj_math.hpp"
+#include "wave_reduce.hpp"
 
 namespace cba {
 
@@ -24,13 +25,6 @@ __device__ __forceinline__ int64_t wave_index() {
     // wave-uniform by construction; readfirstlane lets the compiler keep it (and everything
     // indexed by it) in scalar registers
     return static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-    // fixed butterfly => bitwise reproducible
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 template <int CHAIN>
@@ -190,8 +184,8 @@ __global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, i
             s += rr[0] * rr[0] + rr[1] * rr[1];
         }
     }
-    s = wave_sum(s);
-    if (lane == 0) partial_s[w] = s;
+    s = wave_sum63(s);
+    if (lane == 63) partial_s[w] = s;
 }
 
 // out[b][e] = sum over the block's tiles (in tile order) of partial[t][e]
@@ -286,8 +280,8 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
 #pragma unroll
     for (int e = 0; e < NACC; ++e) {
         if ((e % NPARTS) == PART) {
-            const double s = wave_sum(acc[e]);
-            if (lane == 0) out[e] = s;
+            const double s = wave_sum63(acc[e]);
+            if (lane == 63) out[e] = s;
         }
     }
 }

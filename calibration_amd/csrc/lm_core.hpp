@@ -32,7 +32,7 @@
 namespace cba {
 
 struct TrialStats {
-    double gd = 0, dHd = 0;       // sum_b w g_b^T d, sum_b w d^T H_b d over this rank's blocks
+    double gd = 0, dHd = 0;       // this rank's views' share of g^T d and d^T H d (private + cross terms)
     double step2 = 0, xnorm2 = 0; // private (per-view) share of |x+ - x|^2 and |x|^2
     double cost = 0;              // 1/2 sum_b rho(s_b) at the trial point, this rank's blocks
 };
@@ -137,8 +137,17 @@ class LMDriver {
                     double buf[5] = {st.gd, st.dHd, st.step2, st.xnorm2, st.cost};
                     ar_(buf, 5);
                     st.gd = buf[0]; st.dHd = buf[1]; st.step2 = buf[2]; st.xnorm2 = buf[3]; st.cost = buf[4];
-                    // model_cost_change = -(J d)^T (r + J d / 2)  (trust_region_minimizer.cc)
-                    model_change = -st.gd - 0.5 * st.dHd;
+                    // model_cost_change = -(J d)^T (r + J d / 2) = -g^T d - 1/2 d^T H d (trust_region_minimizer.cc);
+                    // the views contributed their share, the shared-shared part is added here
+                    double gd_sh = 0, dHd_sh = 0;
+                    for (int i = 0; i < n; ++i) {
+                        if (delta[i] == 0.0) continue;
+                        gd_sh += gc_[i] * delta[i];
+                        double s = 0;
+                        for (int j = 0; j < n; ++j) s += Hcc_[static_cast<size_t>(i) * n + j] * delta[j];
+                        dHd_sh += delta[i] * s;
+                    }
+                    model_change = -(st.gd + gd_sh) - 0.5 * (st.dHd + dHd_sh);
                     if (!(model_change > 0.0) || !std::isfinite(model_change)) valid = false;
                 }
                 if (!valid) {

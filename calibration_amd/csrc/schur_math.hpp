@@ -132,21 +132,24 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
 }
 
 // delta_p = -L^-T (y + sum_b Z_b delta_c[cols of b]); trial pose = Plus(x, delta_p).
-// step2 / xnorm2: the view's share of |x_trial - x|^2 and |x|^2 (ambient, 7 numbers).
+// out4 = the view's share of [ |x_trial - x|^2, |x|^2 (ambient, 7 numbers), g^T d, d^T H d ] where the last
+// two are the terms of Ceres' model_cost_change = -g^T d - 1/2 d^T H d that involve the private block:
+//   g_p^T d_p   and   d_p^T H_pp d_p + 2 d_p^T E d_c  =  |rhs|^2 - d_p^T D d_p - 2 rhs^T a,
+// with a = Z d_c, rhs = y + a = -L^T d_p, H_pp = L L^T - D, E = L Z.
 CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, const int32_t* blk_cam, const double* blk_Z,
-                              const double* delta_sh, bool fixed, const double* L, const double* y, const double* x7,
-                              double* delta_p, double* xt7, double* step2, double* xnorm2) {
+                              const double* delta_sh, bool fixed, const double* L, const double* y, const double* D,
+                              const double* gp, const double* x7, double* delta_p, double* xt7, double* out4) {
     double xn = 0.0;
     for (int i = 0; i < 7; ++i) xn += x7[i] * x7[i];
-    *xnorm2 = fixed ? 0.0 : xn;  // constant blocks are not part of Ceres' reduced state vector
+    out4[1] = fixed ? 0.0 : xn;  // constant blocks are not part of Ceres' reduced state vector
     if (fixed) {
         for (int i = 0; i < 6; ++i) delta_p[i] = 0.0;
         for (int i = 0; i < 7; ++i) xt7[i] = x7[i];
-        *step2 = 0.0;
+        out4[0] = out4[2] = out4[3] = 0.0;
         return;
     }
-    double rhs[6];
-    for (int i = 0; i < 6; ++i) rhs[i] = y[i];
+    double a[6], rhs[6];
+    for (int i = 0; i < 6; ++i) a[i] = 0.0;
     for (int k = 0; k < nb; ++k) {
         const int b = blks[k];
         const double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
@@ -154,36 +157,21 @@ CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, c
         for (int i = 0; i < 6; ++i) {
             double s = 0.0;
             for (int c = 0; c < d.PSH; ++c) s += Z[i * d.PSH + c] * dc[c];
-            rhs[i] += s;
+            a[i] += s;
         }
     }
+    double rr = 0.0, ra = 0.0;
+    for (int i = 0; i < 6; ++i) { rhs[i] = y[i] + a[i]; rr += rhs[i] * rhs[i]; ra += rhs[i] * a[i]; }
     bwd6(L, rhs);
-    for (int i = 0; i < 6; ++i) delta_p[i] = -rhs[i];
+    double gd = 0.0, dDd = 0.0;
+    for (int i = 0; i < 6; ++i) { delta_p[i] = -rhs[i]; gd += gp[i] * delta_p[i]; dDd += D[i] * delta_p[i] * delta_p[i]; }
     quat_plus(x7, delta_p, xt7);
     for (int i = 0; i < 3; ++i) xt7[4 + i] = x7[4 + i] + delta_p[3 + i];
     double s2 = 0.0;
     for (int i = 0; i < 7; ++i) s2 += (xt7[i] - x7[i]) * (xt7[i] - x7[i]);
-    *step2 = s2;
-}
-
-// Model-cost terms of one residual block for the step (delta_p, delta_c):
-//   gd = w g_b^T d_loc,   dHd = w d_loc^T H_b d_loc      (model change = -sum gd - 1/2 sum dHd)
-CBA_HD void model_block_body(const SchurDims& d, int cam, const double* acc, double w, const double* delta_p_view,
-                             const double* delta_sh, double* gd, double* dHd) {
-    double dl[24];
-    for (int lc = 0; lc < d.PL; ++lc) {
-        if (d.chain == CH_BUNDLE) dl[lc] = lc < 6 ? delta_sh[lc] : delta_sh[6 + cam * d.PC + (lc - 6)];
-        else dl[lc] = lc < 6 ? delta_p_view[lc] : delta_sh[cam * d.PC + (lc - 6)];
-    }
-    double g = 0.0, q = 0.0;
-    for (int i = 0; i < d.PL; ++i) {
-        g += acc[d.NH + i] * dl[i];
-        double s = 0.0;
-        for (int j = 0; j < d.PL; ++j) s += acc[hidx_sym(d.PL, i, j)] * dl[j];
-        q += dl[i] * s;
-    }
-    *gd = w * g;
-    *dHd = w * q;
+    out4[0] = s2;
+    out4[2] = gd;
+    out4[3] = rr - dDd - 2.0 * ra;
 }
 
 }  // namespace cba

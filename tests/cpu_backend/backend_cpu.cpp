@@ -164,19 +164,15 @@ struct CpuBackend final : Backend {
         *st = TrialStats();
         for (int v = 0; v < s.n_views; ++v) {
             const int nb = static_cast<int>(s.link_off[v + 1] - s.link_off[v]);
-            double s2, x2;
+            double o4[4];
             backsub_view_body(dims, nb, s.link_blk.data() + s.link_off[v], s.blk_cam.data(), blk_Z.data(), delta_sh, fixed[v] != 0,
-                              &vL[36 * static_cast<size_t>(v)], &vy[6 * static_cast<size_t>(v)], &view[0][7 * static_cast<size_t>(v)],
-                              &vdelta[6 * static_cast<size_t>(v)], &view[1][7 * static_cast<size_t>(v)], &s2, &x2);
-            st->step2 += s2;
-            st->xnorm2 += x2;
-        }
-        for (int b = 0; b < s.n_blocks; ++b) {
-            double gd, dHd;
-            const double* dp = s.has_private() ? &vdelta[6 * static_cast<size_t>(s.blk_view[b])] : nullptr;
-            model_block_body(dims, s.blk_cam[b], &blk_acc[static_cast<size_t>(b) * s.NACC], blk_w[b], dp, delta_sh, &gd, &dHd);
-            st->gd += gd;
-            st->dHd += dHd;
+                              &vL[36 * static_cast<size_t>(v)], &vy[6 * static_cast<size_t>(v)], &vD[6 * static_cast<size_t>(v)],
+                              &vgp[6 * static_cast<size_t>(v)], &view[0][7 * static_cast<size_t>(v)], &vdelta[6 * static_cast<size_t>(v)],
+                              &view[1][7 * static_cast<size_t>(v)], o4);
+            st->step2 += o4[0];
+            st->xnorm2 += o4[1];
+            st->gd += o4[2];
+            st->dHd += o4[3];
         }
         consts(1);
         for (int b = 0; b < s.n_blocks; ++b) {
