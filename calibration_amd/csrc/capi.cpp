@@ -283,6 +283,11 @@ cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, 
 int64_t cba_reproj_num_observations(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->n_obs : 0; }
 
 static void ensure_eval_buffers(Engine& e) {
+    if (e.scalar) {
+        const size_t jn = static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A;
+        if (e.Jf.n < jn) e.Jf.alloc(jn);
+        return;
+    }
     if (!e.eval_blocked && e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
     const size_t jn = e.eval_blocked ? static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A : static_cast<size_t>(2 * e.PL) * e.ld;
     if (e.J.n < jn) e.J.alloc(jn);
@@ -329,6 +334,7 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
     return guarded([&] {
         Engine& e = *as_engine(h);
         CBA_HIP(hipSetDevice(e.device));
+        if (e.scalar) throw std::runtime_error("fp32 arithmetic selected: use cba_reproj_eval_fetch_f32");
         if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
         const int P = e.PL;
         if (e.eval_blocked_last) {
@@ -375,6 +381,46 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
                 for (int b = 0; b < e.n_blocks; ++b)
                     for (int64_t i = e.blk_offset[b]; i < e.blk_offset[b + 1]; ++i)
                         J[(2 * i + uvrow) * P + col] = row[e.pad_offset[b] + (i - e.blk_offset[b])];
+            }
+        }
+    });
+}
+
+cba_status cba_reproj_set_scalar(cba_reproj* h, int32_t scalar) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (scalar != 0 && scalar != 1) throw std::invalid_argument("scalar must be 0 (fp64) or 1 (fp32)");
+        CBA_HIP(hipSetDevice(e.device));
+        if (scalar) ensure_f32_buffers(e);
+        e.scalar = scalar;
+        e.eval_done = 0;
+    });
+}
+
+cba_status cba_reproj_eval_fetch_f32(cba_reproj* h, float* r, float* J) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        if (!e.scalar || e.Jf.n == 0 || !e.eval_done) throw std::runtime_error("no fp32 evaluation available");
+        const int P = e.PL;
+        const int64_t tw = static_cast<int64_t>(2 + 2 * P) * TILE_A;
+        std::vector<float> buf(static_cast<size_t>(tw));
+        int64_t w = 0;
+        for (int b = 0; b < e.n_blocks; ++b) {
+            const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
+            for (int64_t s0 = 0; s0 < n; s0 += TILE_A, ++w) {
+                CBA_HIP(hipMemcpyAsync(buf.data(), e.Jf.p + w * tw, sizeof(float) * tw, hipMemcpyDeviceToHost, e.stream));
+                CBA_HIP(hipStreamSynchronize(e.stream));
+                const int64_t cnt = std::min<int64_t>(TILE_A, n - s0);
+                for (int64_t j = 0; j < cnt; ++j) {
+                    const int64_t i = e.blk_offset[b] + s0 + j;
+                    if (r) { r[2 * i] = buf[j]; r[2 * i + 1] = buf[TILE_A + j]; }
+                    if (J)
+                        for (int k = 0; k < P; ++k) {
+                            J[(2 * i) * P + k] = buf[(2 + k) * TILE_A + j];
+                            J[(2 * i + 1) * P + k] = buf[(2 + P + k) * TILE_A + j];
+                        }
+                }
             }
         }
     });

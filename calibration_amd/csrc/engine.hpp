@@ -106,6 +106,9 @@ struct Engine {
 
     // ---- device ------------------------------------------------------------------------------
     DevBuf<double> X, Y, u, v, r, J;
+    // fp32 study (BASELINE config 5): rounded copies of the observations / constant tables, fp32 Mode A output
+    int scalar = 0;  // 0 = fp64 per-observation arithmetic, 1 = fp32 (accumulators stay fp64)
+    DevBuf<float> Xf, Yf, uf, vf, Jf, bcf, sdf, intrf;
     DevBuf<double> bc, sd, aux;  // aux: bundle b_T_g [n_blocks][12]
     DevBuf<double> intr[2], cam[2], view[2], target[2];
     int eval_blocked = 1;  // Mode A output layout: 1 tile-blocked out[tile][2+2P][128] (default), 0 whole-array columns
@@ -146,6 +149,7 @@ struct Engine {
 };
 
 // kernels_reproj.hip
+void ensure_f32_buffers(Engine& e);                      // fp32 copies of the observations + float tables
 void launch_block_consts(Engine& e, int which);         // params[which] -> bc, sd
 void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
 void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2

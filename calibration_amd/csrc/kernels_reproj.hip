@@ -30,7 +30,8 @@ __device__ __forceinline__ int64_t wave_index() {
 template <int CHAIN>
 __global__ void k_block_consts(int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
                                const double* __restrict__ cam, const double* __restrict__ view,
-                               const double* __restrict__ target, const double* __restrict__ aux, double* __restrict__ bc) {
+                               const double* __restrict__ target, const double* __restrict__ aux, double* __restrict__ bc,
+                               float* __restrict__ bcf) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const double *pA, *pB = nullptr, *ax = nullptr;
@@ -47,27 +48,40 @@ __global__ void k_block_consts(int n_blocks, const int32_t* __restrict__ blk_cam
     double out[BC_SIZE];
     block_consts<CHAIN>(pA, pB, ax, out);
     for (int i = 0; i < BC_SIZE; ++i) bc[static_cast<int64_t>(b) * BC_SIZE + i] = out[i];
+    if (bcf)
+        for (int i = 0; i < BC_SIZE; ++i) bcf[static_cast<int64_t>(b) * BC_SIZE + i] = static_cast<float>(out[i]);
 }
 
-__global__ void k_scheimpflug_consts(int n_cams, const double* __restrict__ intr, double* __restrict__ sd) {
+__global__ void k_scheimpflug_consts(int n_cams, const double* __restrict__ intr, double* __restrict__ sd,
+                                     float* __restrict__ sdf) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cams) return;
     double out[SD_SIZE];
     for (int i = 0; i < SD_SIZE; ++i) out[i] = 0.0;
     scheimpflug_consts(intr + 12 * static_cast<int64_t>(c), out);
     for (int i = 0; i < SD_SIZE; ++i) sd[static_cast<int64_t>(c) * SD_SIZE + i] = out[i];
+    if (sdf)
+        for (int i = 0; i < SD_SIZE; ++i) sdf[static_cast<int64_t>(c) * SD_SIZE + i] = static_cast<float>(out[i]);
+}
+
+__global__ void k_to_f32(int64_t n, const double* __restrict__ in, float* __restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = static_cast<float>(in[i]);
 }
 
 // ---- Mode A -----------------------------------------------------------------------------------
 // Algorithmic HBM traffic per observation: 4 loads + 2 residual stores + 2*P Jacobian stores of
 // 8 bytes = 304 B (P=16) ... 432 B (P=24).  HBM-bound: ~0.3 kFLOP per observation.
-typedef double d2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct Pair;
+template <> struct Pair<double> { typedef double vec __attribute__((ext_vector_type(2))); using ld = double2; };
+template <> struct Pair<float> { typedef float vec __attribute__((ext_vector_type(2))); using ld = float2; };
 
-template <bool NT>
-__device__ __forceinline__ void store2(double* p, double a, double b) {
-    d2_t v = {a, b};
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(p));
-    else *reinterpret_cast<d2_t*>(p) = v;
+// two adjacent observations per lane: one 16-byte (fp64) / 8-byte (fp32) access
+template <bool NT, typename T>
+__device__ __forceinline__ void store2(T* p, T a, T b) {
+    typename Pair<T>::vec v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<typename Pair<T>::vec*>(p));
+    else *reinterpret_cast<typename Pair<T>::vec*>(p) = v;
 }
 
 // NT: non-temporal (streaming) stores for r / J, which this kernel never re-reads.
@@ -80,13 +94,14 @@ __device__ __forceinline__ void store2(double* p, double a, double b) {
 // k+1 BEFORE it computes and stores tile k, so the ~2 us load latency under a write-saturated memory
 // system hides behind 34 KiB of stores instead of stalling the wave (measured: loads are 10 % of the
 // bytes but cost 15 % of the time when they sit at the head of every wave).
-template <int CHAIN, int MODEL, bool NT, int ROWS, bool BLK, int ABL = 0>
+template <int CHAIN, int MODEL, bool NT, int ROWS, bool BLK, int ABL = 0, typename T = double>
 __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, int64_t n_tiles,
-                                              const double* __restrict__ bc, const double* __restrict__ intr,
-                                              const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
-                                              const double* __restrict__ X, const double* __restrict__ Y,
-                                              const double* __restrict__ u, const double* __restrict__ v,
-                                              double* __restrict__ r, double* __restrict__ J, int64_t ld) {
+                                              const T* __restrict__ bc, const T* __restrict__ intr,
+                                              const T* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                              const T* __restrict__ X, const T* __restrict__ Y,
+                                              const T* __restrict__ u, const T* __restrict__ v,
+                                              T* __restrict__ r, T* __restrict__ J, int64_t ld) {
+    using V2 = typename Pair<T>::ld;
     constexpr int PI = IntrSize<MODEL>::value;
     constexpr int PL = LocalCols<CHAIN, MODEL>::value;
     const int lane = threadIdx.x & 63;
@@ -95,60 +110,60 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, in
     const int64_t w1 = (w0 + ROWS < n_tiles) ? w0 + ROWS : n_tiles;
 
     Tile t = tiles[w0];
-    double2 Xv, Yv, uv, vv;
-    auto load_obs = [&](const Tile& tt, double2& a, double2& b, double2& c, double2& d) {
+    V2 Xv, Yv, uv, vv;
+    auto load_obs = [&](const Tile& tt, V2& a, V2& b, V2& c, V2& d) {
         if (ABL == 2) {
-            a = make_double2(1e-3 * lane, 2e-3 * lane); b = make_double2(-1e-3 * lane, 1e-3);
-            c = make_double2(600.0, 610.0); d = make_double2(300.0, 310.0);
+            a.x = T(1e-3) * lane; a.y = T(2e-3) * lane; b.x = T(-1e-3) * lane; b.y = T(1e-3);
+            c.x = T(600); c.y = T(610); d.x = T(300); d.y = T(310);
         } else {
             // lanes past the tile's end read the tile's first pair (in bounds, result unused)
             const int64_t i = tt.start + ((2 * lane < tt.count) ? 2 * lane : 0);
-            a = *reinterpret_cast<const double2*>(X + i);
-            b = *reinterpret_cast<const double2*>(Y + i);
-            c = *reinterpret_cast<const double2*>(u + i);
-            d = *reinterpret_cast<const double2*>(v + i);
+            a = *reinterpret_cast<const V2*>(X + i);
+            b = *reinterpret_cast<const V2*>(Y + i);
+            c = *reinterpret_cast<const V2*>(u + i);
+            d = *reinterpret_cast<const V2*>(v + i);
         }
     };
     load_obs(t, Xv, Yv, uv, vv);
 #pragma unroll 1
     for (int64_t w = w0; w < w1; ++w) {
         Tile tn = t;
-        double2 Xn = Xv, Yn = Yv, un = uv, vn = vv;
+        V2 Xn = Xv, Yn = Yv, un = uv, vn = vv;
         if (ROWS > 1 && w + 1 < w1) {
             tn = tiles[w + 1];
             load_obs(tn, Xn, Yn, un, vn);
         }
         if (2 * lane < t.count) {
-            const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+            const T* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
             const int cam = blk_cam[t.blk];
-            const double* ip = intr + static_cast<int64_t>(cam) * PI;
-            const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+            const T* ip = intr + static_cast<int64_t>(cam) * PI;
+            const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
             const int64_t i0 = t.start + 2 * lane;
-            double r0[2], r1[2], Ju0[PL], Jv0[PL], Ju1[PL], Jv1[PL];
+            T r0[2], r1[2], Ju0[PL], Jv0[PL], Ju1[PL], Jv1[PL];
             if (ABL == 1) {
                 r0[0] = Xv.x; r0[1] = Yv.x; r1[0] = uv.x; r1[1] = vv.x;
 #pragma unroll
                 for (int k = 0; k < PL; ++k) { Ju0[k] = Xv.y + k; Jv0[k] = Yv.y; Ju1[k] = uv.y; Jv1[k] = vv.y + k; }
             } else {
-                reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.x, Yv.x, uv.x, vv.x, r0, Ju0, Jv0);
-                reproj_point<CHAIN, MODEL>(bcp, ip, sp, Xv.y, Yv.y, uv.y, vv.y, r1, Ju1, Jv1);
+                reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, Xv.x, Yv.x, uv.x, vv.x, r0, Ju0, Jv0);
+                reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, Xv.y, Yv.y, uv.y, vv.y, r1, Ju1, Jv1);
             }
             if (BLK) {
-                double* o = J + w * static_cast<int64_t>((2 + 2 * PL) * TILE_A) + 2 * lane;
-                store2<NT>(o, r0[0], r1[0]);
-                store2<NT>(o + TILE_A, r0[1], r1[1]);
+                T* o = J + w * static_cast<int64_t>((2 + 2 * PL) * TILE_A) + 2 * lane;
+                store2<NT, T>(o, r0[0], r1[0]);
+                store2<NT, T>(o + TILE_A, r0[1], r1[1]);
 #pragma unroll
                 for (int k = 0; k < PL; ++k) {
-                    store2<NT>(o + (2 + k) * TILE_A, Ju0[k], Ju1[k]);
-                    store2<NT>(o + (2 + PL + k) * TILE_A, Jv0[k], Jv1[k]);
+                    store2<NT, T>(o + (2 + k) * TILE_A, Ju0[k], Ju1[k]);
+                    store2<NT, T>(o + (2 + PL + k) * TILE_A, Jv0[k], Jv1[k]);
                 }
             } else {
-                store2<NT>(r + i0, r0[0], r1[0]);
-                store2<NT>(r + ld + i0, r0[1], r1[1]);
+                store2<NT, T>(r + i0, r0[0], r1[0]);
+                store2<NT, T>(r + ld + i0, r0[1], r1[1]);
 #pragma unroll
                 for (int k = 0; k < PL; ++k) {
-                    store2<NT>(J + static_cast<int64_t>(k) * ld + i0, Ju0[k], Ju1[k]);
-                    store2<NT>(J + static_cast<int64_t>(PL + k) * ld + i0, Jv0[k], Jv1[k]);
+                    store2<NT, T>(J + static_cast<int64_t>(k) * ld + i0, Ju0[k], Ju1[k]);
+                    store2<NT, T>(J + static_cast<int64_t>(PL + k) * ld + i0, Jv0[k], Jv1[k]);
                 }
             }
         }
@@ -157,31 +172,31 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, in
 }
 
 // ---- Mode R -----------------------------------------------------------------------------------
-template <int MODEL>
+template <int MODEL, typename T>
 __global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, int64_t n_tiles,
-                                               const double* __restrict__ bc, const double* __restrict__ intr,
-                                               const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
-                                               const double* __restrict__ X, const double* __restrict__ Y,
-                                               const double* __restrict__ u, const double* __restrict__ v,
+                                               const T* __restrict__ bc, const T* __restrict__ intr,
+                                               const T* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                               const T* __restrict__ X, const T* __restrict__ Y,
+                                               const T* __restrict__ u, const T* __restrict__ v,
                                                double* __restrict__ partial_s) {
     constexpr int PI = IntrSize<MODEL>::value;
     const int64_t w = wave_index();
     if (w >= n_tiles) return;
     const Tile t = tiles[w];
     const int lane = threadIdx.x & 63;
-    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const T* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
     const int cam = blk_cam[t.blk];
-    const double* ip = intr + static_cast<int64_t>(cam) * PI;
-    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+    const T* ip = intr + static_cast<int64_t>(cam) * PI;
+    const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < OPL_B; ++k) {
         const int j = lane + 64 * k;
         if (j < t.count) {
             const int64_t i = t.start + j;
-            double rr[2];
-            reproj_residual<MODEL>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr);
-            s += rr[0] * rr[0] + rr[1] * rr[1];
+            T rr[2];
+            reproj_residual<MODEL, T>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr);
+            s += static_cast<double>(rr[0]) * rr[0] + static_cast<double>(rr[1]) * rr[1];
         }
     }
     s = wave_sum63(s);
@@ -229,12 +244,13 @@ __global__ __launch_bounds__(256) void k_cost(int n_blocks, const double* __rest
 // UNWEIGHTED (the per-block Huber weight is a scalar applied when blocks are assembled).
 // The packed accumulator vector [H | g | s] is split round-robin over NPARTS launches so that one
 // lane's share stays in registers; every part re-evaluates the (cheap) Jacobian rows.
-template <int CHAIN, int MODEL, int NPARTS, int PART>
+// T = float: the Jacobian rows are evaluated in fp32 and widened once; every accumulator stays fp64.
+template <int CHAIN, int MODEL, int NPARTS, int PART, typename T>
 __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tiles, int64_t n_tiles,
-                                                   const double* __restrict__ bc, const double* __restrict__ intr,
-                                                   const double* __restrict__ sd, const int32_t* __restrict__ blk_cam,
-                                                   const double* __restrict__ X, const double* __restrict__ Y,
-                                                   const double* __restrict__ u, const double* __restrict__ v,
+                                                   const T* __restrict__ bc, const T* __restrict__ intr,
+                                                   const T* __restrict__ sd, const int32_t* __restrict__ blk_cam,
+                                                   const T* __restrict__ X, const T* __restrict__ Y,
+                                                   const T* __restrict__ u, const T* __restrict__ v,
                                                    double* __restrict__ partial) {
     constexpr int PI = IntrSize<MODEL>::value;
     constexpr int PL = LocalCols<CHAIN, MODEL>::value;
@@ -244,10 +260,10 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
     if (w >= n_tiles) return;
     const Tile t = tiles[w];
     const int lane = threadIdx.x & 63;
-    const double* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const T* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
     const int cam = blk_cam[t.blk];
-    const double* ip = intr + static_cast<int64_t>(cam) * PI;
-    const double* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+    const T* ip = intr + static_cast<int64_t>(cam) * PI;
+    const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
 
     double acc[NACC];
 #pragma unroll
@@ -258,8 +274,12 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
         const int j = lane + 64 * k;
         if (j < t.count) {
             const int64_t i = t.start + j;
+            T rt[2], Jut[PL], Jvt[PL];
+            reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rt, Jut, Jvt);
             double rr[2], Ju[PL], Jv[PL];
-            reproj_point<CHAIN, MODEL>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr, Ju, Jv);
+            rr[0] = rt[0]; rr[1] = rt[1];
+#pragma unroll
+            for (int a = 0; a < PL; ++a) { Ju[a] = Jut[a]; Jv[a] = Jvt[a]; }
             int e = 0;
 #pragma unroll
             for (int a = 0; a < PL; ++a) {
@@ -300,6 +320,22 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
 
 static inline unsigned blocks_for(int64_t n, int per) { return static_cast<unsigned>((n + per - 1) / per); }
 
+void ensure_f32_buffers(Engine& e) {
+    if (e.Xf.n >= static_cast<size_t>(e.ld) && e.bcf.n > 0) return;
+    const DevBuf<double>* src[4] = {&e.X, &e.Y, &e.u, &e.v};
+    DevBuf<float>* dst[4] = {&e.Xf, &e.Yf, &e.uf, &e.vf};
+    for (int a = 0; a < 4; ++a) {
+        dst[a]->alloc(static_cast<size_t>(e.ld));
+        hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(e.ld, 256)), dim3(256), 0, e.stream, e.ld, src[a]->p, dst[a]->p);
+    }
+    e.bcf.alloc(static_cast<size_t>(std::max(1, e.n_blocks)) * BC_SIZE);
+    e.sdf.alloc(static_cast<size_t>(e.n_cams) * SD_SIZE);
+    e.intrf.alloc(static_cast<size_t>(e.n_cams) * e.PI);
+    CBA_HIP(hipMemsetAsync(e.sdf.p, 0, e.sdf.n * sizeof(float), e.stream));
+    CBA_HIP(hipGetLastError());
+    CBA_HIP(hipStreamSynchronize(e.stream));
+}
+
 void launch_block_consts(Engine& e, int which) {
     e.active = which;
     if (e.n_blocks == 0) return;
@@ -307,22 +343,26 @@ void launch_block_consts(Engine& e, int which) {
     const double* cam = e.cam[which].p;
     const double* view = e.view[which].p;
     const double* target = e.target[which].p;
+    float* bcf = e.scalar ? e.bcf.p : nullptr;
     switch (e.chain) {
         case CH_INTRINSIC:
             hipLaunchKernelGGL(k_block_consts<CH_INTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
-                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
             break;
         case CH_EXTRINSIC:
             hipLaunchKernelGGL(k_block_consts<CH_EXTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
-                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
             break;
         default:
             hipLaunchKernelGGL(k_block_consts<CH_BUNDLE>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
-                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p);
+                               e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
     }
     if (e.model == CAM_SCHEIMPFLUG)
         hipLaunchKernelGGL(k_scheimpflug_consts, dim3(blocks_for(e.n_cams, 64)), dim3(64), 0, e.stream, e.n_cams,
-                           e.intr[which].p, e.sd.p);
+                           e.intr[which].p, e.sd.p, e.scalar ? e.sdf.p : nullptr);
+    if (e.scalar)
+        hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(static_cast<int64_t>(e.n_cams) * e.PI, 64)), dim3(64), 0, e.stream,
+                           static_cast<int64_t>(e.n_cams) * e.PI, e.intr[which].p, e.intrf.p);
     CBA_HIP(hipGetLastError());
 }
 
@@ -332,22 +372,35 @@ static const double* intr_of(Engine& e) { return e.intr[e.active].p; }
 template <int C, int M, bool NT, int ROWS>
 static void launch_eval_v(Engine& e) {
     const unsigned g = blocks_for(e.n_tilesA, 4 * ROWS);
+#define CBA_EVAL_ARGS dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p, intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, \
+                      e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld
     if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 1)
-        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), CBA_EVAL_ARGS);
     else if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 2)
-        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), CBA_EVAL_ARGS);
     else if (e.eval_blocked)
-        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), CBA_EVAL_ARGS);
     else
-        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld);
+        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), CBA_EVAL_ARGS);
+#undef CBA_EVAL_ARGS
+}
+
+template <int C, int M>
+static void launch_eval_f32(Engine& e) {  // fp32 study: tile-blocked, non-temporal, one tile per wave
+    const unsigned g = blocks_for(e.n_tilesA, 4);
+    hipLaunchKernelGGL((k_eval<C, M, true, 1, true, 0, float>), dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bcf.p,
+                       e.intrf.p, e.sdf.p, e.d_blk_cam.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, static_cast<float*>(nullptr), e.Jf.p, e.ld);
 }
 
 void launch_eval(Engine& e) {
     if (e.n_tilesA == 0) return;
+    if (e.scalar) {
+#define CALL(C, M) launch_eval_f32<C, M>(e);
+        CBA_DISPATCH(e, CALL)
+#undef CALL
+        CBA_HIP(hipGetLastError());
+        return;
+    }
     // tuning knob (experiments only; read at handle creation): bit 0 = nt stores, bits 1.. = log2(tiles per wave)
     const int variant = e.eval_variant;
 #define CALL(C, M)                                                         \
@@ -369,12 +422,14 @@ void launch_eval(Engine& e) {
 void launch_resid(Engine& e) {
     if (e.n_tilesB == 0) return;
     const unsigned g = blocks_for(e.n_tilesB, 4);
-    if (e.model == CAM_PINHOLE_BC)
-        hipLaunchKernelGGL(k_resid<CAM_PINHOLE_BC>, dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
-    else
-        hipLaunchKernelGGL(k_resid<CAM_SCHEIMPFLUG>, dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
-                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
+#define RESID_F64(M) hipLaunchKernelGGL((k_resid<M, double>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p, \
+                                        intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p)
+#define RESID_F32(M) hipLaunchKernelGGL((k_resid<M, float>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bcf.p, \
+                                        e.intrf.p, e.sdf.p, e.d_blk_cam.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, e.partial.p)
+    if (e.model == CAM_PINHOLE_BC) { if (e.scalar) RESID_F32(CAM_PINHOLE_BC); else RESID_F64(CAM_PINHOLE_BC); }
+    else { if (e.scalar) RESID_F32(CAM_SCHEIMPFLUG); else RESID_F64(CAM_SCHEIMPFLUG); }
+#undef RESID_F64
+#undef RESID_F32
     hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(e.n_blocks, 256)), dim3(256), 0, e.stream, e.n_blocks, 1,
                        e.d_blk_tile_off.p, e.partial.p, e.blk_s.p);
     CBA_HIP(hipGetLastError());
@@ -387,8 +442,12 @@ void launch_cost(Engine& e, double huber_delta) {
 
 template <int C, int M, int NP, int PART>
 static void launch_ne_part(Engine& e, unsigned g) {
-    hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
-                       intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
+    if (e.scalar)
+        hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART, float>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bcf.p,
+                           e.intrf.p, e.sdf.p, e.d_blk_cam.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, e.partial.p);
+    else
+        hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART, double>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
+                           intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.partial.p);
 }
 template <int C, int M>
 static void launch_ne(Engine& e, unsigned g) {

@@ -131,56 +131,65 @@ CBA_HD void cross3(const double* a, const double* b, double* c) {
 }
 
 // Residual only.  bc: block constants, intr: camera params, sd: Scheimpflug constants (unused for
-// pinhole).  Returns r = (u - u_obs, v - v_obs).
-template <int MODEL>
-CBA_HD void reproj_residual(const double* bc, const double* intr, const double* sd, double X, double Y, double uo,
-                            double vo, double* r) {
-    const double P0 = X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0];
-    const double P1 = X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1];
-    const double P2 = X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2];
-    double x, y, su = 0.0, sv = 0.0;
+// pinhole), all already in the arithmetic type T (double, or float for the fp32 study of BASELINE
+// config 5).  Returns r = (u - u_obs, v - v_obs).
+template <int MODEL, typename T>
+CBA_HD void reproj_residual(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, T* r) {
+    const T P0 = X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0];
+    const T P1 = X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1];
+    const T P2 = X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2];
+    T x, y, su = T(0), sv = T(0);
     if (MODEL == CAM_PINHOLE_BC) {
-        const double iz = 1.0 / P2;
+        const T iz = T(1) / P2;
         x = P0 * iz; y = P1 * iz;
     } else {
-        const double* Rs = sd + SD_RS;
-        const double is = 1.0 / (Rs[2] * P0 + Rs[5] * P1 + Rs[8] * P2);
+        const T* Rs = sd + SD_RS;
+        const T is = T(1) / (Rs[2] * P0 + Rs[5] * P1 + Rs[8] * P2);
         x = (Rs[0] * P0 + Rs[3] * P1 + Rs[6] * P2) * is - sd[SD_M0];
         y = (Rs[1] * P0 + Rs[4] * P1 + Rs[7] * P2) * is - sd[SD_M0 + 1];
         su = intr[0] * sd[SD_M0] + intr[4] * sd[SD_M0 + 1];
         sv = intr[1] * sd[SD_M0 + 1];
     }
-    const double r2 = x * x + y * y;
-    const double rad = 1.0 + r2 * (intr[5] + r2 * (intr[6] + r2 * intr[7]));
-    const double xy = x * y;
-    const double xd = x * rad + 2.0 * intr[8] * xy + intr[9] * (r2 + 2.0 * x * x);
-    const double yd = y * rad + intr[8] * (r2 + 2.0 * y * y) + 2.0 * intr[9] * xy;
+    const T r2 = x * x + y * y;
+    const T rad = T(1) + r2 * (intr[5] + r2 * (intr[6] + r2 * intr[7]));
+    const T xy = x * y;
+    const T xd = x * rad + T(2) * intr[8] * xy + intr[9] * (r2 + T(2) * x * x);
+    const T yd = y * rad + intr[8] * (r2 + T(2) * y * y) + T(2) * intr[9] * xy;
     r[0] = (intr[0] * xd + intr[4] * yd + intr[2] + su) - uo;
     r[1] = (intr[1] * yd + intr[3] + sv) - vo;
 }
 
-// Residual + Jacobian rows.  Ju/Jv: LocalCols<CHAIN,MODEL>::value entries each.
-template <int CHAIN, int MODEL>
-CBA_HD void reproj_point(const double* bc, const double* intr, const double* sd, double X, double Y, double uo,
-                         double vo, double* r, double* Ju, double* Jv) {
-    constexpr int PI = IntrSize<MODEL>::value;
-    constexpr int OI = CHAIN == CH_INTRINSIC ? 6 : 12;  // offset of the intrinsics columns
-    const double fx = intr[0], fy = intr[1], skew = intr[4];
-    const double k1 = intr[5], k2 = intr[6], k3 = intr[7], p1 = intr[8], p2 = intr[9];
+template <typename T>
+CBA_HD void cross3t(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T>
+CBA_HD void mat3_tvec_t(const T* A, const T* x, T* y) {  // y = A^T x
+    for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
 
-    const double P[3] = {X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0],
-                         X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1],
-                         X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2]};
+// Residual + Jacobian rows.  Ju/Jv: LocalCols<CHAIN,MODEL>::value entries each.
+template <int CHAIN, int MODEL, typename T>
+CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, T* r, T* Ju, T* Jv) {
+    constexpr int OI = CHAIN == CH_INTRINSIC ? 6 : 12;  // offset of the intrinsics columns
+    const T fx = intr[0], fy = intr[1], skew = intr[4];
+    const T k1 = intr[5], k2 = intr[6], k3 = intr[7], p1 = intr[8], p2 = intr[9];
+
+    const T P[3] = {X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0],
+                    X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1],
+                    X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2]};
     // (x, y) = normalised coordinates fed to Brown-Conrady and d(x,y)/dP rows gx, gy
-    double x, y, gx[3], gy[3], m0x = 0.0, m0y = 0.0, mx = 0.0, my = 0.0, is = 0.0;
+    T x, y, gx[3], gy[3], m0x = T(0), m0y = T(0), mx = T(0), my = T(0), is = T(0);
     if (MODEL == CAM_PINHOLE_BC) {
-        const double iz = 1.0 / P[2];
+        const T iz = T(1) / P[2];
         x = P[0] * iz; y = P[1] * iz;
-        gx[0] = iz; gx[1] = 0.0; gx[2] = -x * iz;
-        gy[0] = 0.0; gy[1] = iz; gy[2] = -y * iz;
+        gx[0] = iz; gx[1] = T(0); gx[2] = -x * iz;
+        gy[0] = T(0); gy[1] = iz; gy[2] = -y * iz;
     } else {
-        const double* Rs = sd + SD_RS;
-        is = 1.0 / (Rs[2] * P[0] + Rs[5] * P[1] + Rs[8] * P[2]);
+        const T* Rs = sd + SD_RS;
+        is = T(1) / (Rs[2] * P[0] + Rs[5] * P[1] + Rs[8] * P[2]);
         mx = (Rs[0] * P[0] + Rs[3] * P[1] + Rs[6] * P[2]) * is;
         my = (Rs[1] * P[0] + Rs[4] * P[1] + Rs[7] * P[2]) * is;
         m0x = sd[SD_M0]; m0y = sd[SD_M0 + 1];
@@ -190,63 +199,63 @@ CBA_HD void reproj_point(const double* bc, const double* intr, const double* sd,
             gy[i] = (Rs[3 * i + 1] - my * Rs[3 * i + 2]) * is;
         }
     }
-    const double r2 = x * x + y * y, xx = x * x, yy = y * y, xy = x * y;
-    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
-    const double drad = k1 + r2 * (2.0 * k2 + 3.0 * k3 * r2);
-    const double xd = x * rad + 2.0 * p1 * xy + p2 * (r2 + 2.0 * xx);
-    const double yd = y * rad + p1 * (r2 + 2.0 * yy) + 2.0 * p2 * xy;
+    const T r2 = x * x + y * y, xx = x * x, yy = y * y, xy = x * y;
+    const T rad = T(1) + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const T drad = k1 + r2 * (T(2) * k2 + T(3) * k3 * r2);
+    const T xd = x * rad + T(2) * p1 * xy + p2 * (r2 + T(2) * xx);
+    const T yd = y * rad + p1 * (r2 + T(2) * yy) + T(2) * p2 * xy;
     r[0] = (fx * xd + skew * yd + intr[2] + (fx * m0x + skew * m0y)) - uo;
     r[1] = (fy * yd + intr[3] + fy * m0y) - vo;
 
     // d(xd,yd)/d(x,y)
-    const double dxdx = rad + 2.0 * xx * drad + 2.0 * p1 * y + 6.0 * p2 * x;
-    const double dxdy = 2.0 * xy * drad + 2.0 * p1 * x + 2.0 * p2 * y;  // = dyd/dx
-    const double dydy = rad + 2.0 * yy * drad + 6.0 * p1 * y + 2.0 * p2 * x;
+    const T dxdx = rad + T(2) * xx * drad + T(2) * p1 * y + T(6) * p2 * x;
+    const T dxdy = T(2) * xy * drad + T(2) * p1 * x + T(2) * p2 * y;  // = dyd/dx
+    const T dydy = rad + T(2) * yy * drad + T(6) * p1 * y + T(2) * p2 * x;
     // d(u,v)/d(x,y)
-    const double ux = fx * dxdx + skew * dxdy, uy = fx * dxdy + skew * dydy;
-    const double vx = fy * dxdy, vy = fy * dydy;
+    const T ux = fx * dxdx + skew * dxdy, uy = fx * dxdy + skew * dydy;
+    const T vx = fy * dxdy, vy = fy * dydy;
     // d(u,v)/dP
-    double du[3], dv[3];
+    T du[3], dv[3];
     for (int i = 0; i < 3; ++i) { du[i] = ux * gx[i] + uy * gy[i]; dv[i] = vx * gx[i] + vy * gy[i]; }
 
     // ---- pose A: dP/d(delta_A) = -2 M [c]x, dP/d(t_A) = M,  c = X a1 + Y a2 ----
-    const double c[3] = {X * bc[BC_A1] + Y * bc[BC_A2], X * bc[BC_A1 + 1] + Y * bc[BC_A2 + 1],
-                         X * bc[BC_A1 + 2] + Y * bc[BC_A2 + 2]};
-    double eu[3], ev[3], cr[3];
+    const T c[3] = {X * bc[BC_A1] + Y * bc[BC_A2], X * bc[BC_A1 + 1] + Y * bc[BC_A2 + 1],
+                    X * bc[BC_A1 + 2] + Y * bc[BC_A2 + 2]};
+    T eu[3], ev[3], cr[3];
     if (CHAIN == CH_INTRINSIC) {
         for (int i = 0; i < 3; ++i) { eu[i] = du[i]; ev[i] = dv[i]; }
     } else {
-        mat3_tvec(bc + BC_M, du, eu);  // row vector du^T M
-        mat3_tvec(bc + BC_M, dv, ev);
+        mat3_tvec_t(bc + BC_M, du, eu);  // row vector du^T M
+        mat3_tvec_t(bc + BC_M, dv, ev);
     }
-    cross3(c, eu, cr); for (int i = 0; i < 3; ++i) { Ju[i] = 2.0 * cr[i]; Ju[3 + i] = eu[i]; }
-    cross3(c, ev, cr); for (int i = 0; i < 3; ++i) { Jv[i] = 2.0 * cr[i]; Jv[3 + i] = ev[i]; }
+    cross3t(c, eu, cr); for (int i = 0; i < 3; ++i) { Ju[i] = T(2) * cr[i]; Ju[3 + i] = eu[i]; }
+    cross3t(c, ev, cr); for (int i = 0; i < 3; ++i) { Jv[i] = T(2) * cr[i]; Jv[3 + i] = ev[i]; }
 
     // ---- pose B ----
     if (CHAIN == CH_EXTRINSIC) {
         // dP/d(delta_B) = -2 [P - t_cr]x, dP/d(t_B) = I
-        const double w[3] = {P[0] - bc[BC_TB], P[1] - bc[BC_TB + 1], P[2] - bc[BC_TB + 2]};
-        cross3(w, du, cr); for (int i = 0; i < 3; ++i) { Ju[6 + i] = 2.0 * cr[i]; Ju[9 + i] = du[i]; }
-        cross3(w, dv, cr); for (int i = 0; i < 3; ++i) { Jv[6 + i] = 2.0 * cr[i]; Jv[9 + i] = dv[i]; }
+        const T w[3] = {P[0] - bc[BC_TB], P[1] - bc[BC_TB + 1], P[2] - bc[BC_TB + 2]};
+        cross3t(w, du, cr); for (int i = 0; i < 3; ++i) { Ju[6 + i] = T(2) * cr[i]; Ju[9 + i] = du[i]; }
+        cross3t(w, dv, cr); for (int i = 0; i < 3; ++i) { Jv[6 + i] = T(2) * cr[i]; Jv[9 + i] = dv[i]; }
     } else if (CHAIN == CH_BUNDLE) {
         // dP/d(delta_B) = 2 [P]x N, dP/d(t_B) = -N,  N = R_gc^T
-        double h[3], hn[3], dn[3];
-        cross3(du, P, h); mat3_tvec(bc + BC_N, h, hn); mat3_tvec(bc + BC_N, du, dn);
-        for (int i = 0; i < 3; ++i) { Ju[6 + i] = 2.0 * hn[i]; Ju[9 + i] = -dn[i]; }
-        cross3(dv, P, h); mat3_tvec(bc + BC_N, h, hn); mat3_tvec(bc + BC_N, dv, dn);
-        for (int i = 0; i < 3; ++i) { Jv[6 + i] = 2.0 * hn[i]; Jv[9 + i] = -dn[i]; }
+        T h[3], hn[3], dn[3];
+        cross3t(du, P, h); mat3_tvec_t(bc + BC_N, h, hn); mat3_tvec_t(bc + BC_N, du, dn);
+        for (int i = 0; i < 3; ++i) { Ju[6 + i] = T(2) * hn[i]; Ju[9 + i] = -dn[i]; }
+        cross3t(dv, P, h); mat3_tvec_t(bc + BC_N, h, hn); mat3_tvec_t(bc + BC_N, dv, dn);
+        for (int i = 0; i < 3; ++i) { Jv[6 + i] = T(2) * hn[i]; Jv[9 + i] = -dn[i]; }
     }
 
     // ---- intrinsics [fx fy cx cy skew k1 k2 k3 p1 p2 (tau_x tau_y)] ----
-    const double r4 = r2 * r2, r6 = r4 * r2;
-    const double t1x = 2.0 * xy, t1y = r2 + 2.0 * yy;  // d(xd,yd)/dp1
-    const double t2x = r2 + 2.0 * xx, t2y = 2.0 * xy;  // d(xd,yd)/dp2
-    Ju[OI + 0] = xd + m0x; Jv[OI + 0] = 0.0;
-    Ju[OI + 1] = 0.0;      Jv[OI + 1] = yd + m0y;
-    Ju[OI + 2] = 1.0;      Jv[OI + 2] = 0.0;
-    Ju[OI + 3] = 0.0;      Jv[OI + 3] = 1.0;
-    Ju[OI + 4] = yd + m0y; Jv[OI + 4] = 0.0;
-    const double gu = fx * x + skew * y, gv = fy * y;
+    const T r4 = r2 * r2, r6 = r4 * r2;
+    const T t1x = T(2) * xy, t1y = r2 + T(2) * yy;  // d(xd,yd)/dp1
+    const T t2x = r2 + T(2) * xx, t2y = T(2) * xy;  // d(xd,yd)/dp2
+    Ju[OI + 0] = xd + m0x; Jv[OI + 0] = T(0);
+    Ju[OI + 1] = T(0);     Jv[OI + 1] = yd + m0y;
+    Ju[OI + 2] = T(1);     Jv[OI + 2] = T(0);
+    Ju[OI + 3] = T(0);     Jv[OI + 3] = T(1);
+    Ju[OI + 4] = yd + m0y; Jv[OI + 4] = T(0);
+    const T gu = fx * x + skew * y, gv = fy * y;
     Ju[OI + 5] = gu * r2;  Jv[OI + 5] = gv * r2;
     Ju[OI + 6] = gu * r4;  Jv[OI + 6] = gv * r4;
     Ju[OI + 7] = gu * r6;  Jv[OI + 7] = gv * r6;
@@ -255,17 +264,16 @@ CBA_HD void reproj_point(const double* bc, const double* intr, const double* sd,
     if (MODEL == CAM_SCHEIMPFLUG) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const double* D = sd + (k == 0 ? SD_DX : SD_DY);
-            const double* dm0 = sd + (k == 0 ? SD_DM0X : SD_DM0Y);
-            const double dnP = D[2] * P[0] + D[5] * P[1] + D[8] * P[2];
-            const double dmx = ((D[0] * P[0] + D[3] * P[1] + D[6] * P[2]) - mx * dnP) * is;
-            const double dmy = ((D[1] * P[0] + D[4] * P[1] + D[7] * P[2]) - my * dnP) * is;
-            const double dx = dmx - dm0[0], dy = dmy - dm0[1];
+            const T* D = sd + (k == 0 ? SD_DX : SD_DY);
+            const T* dm0 = sd + (k == 0 ? SD_DM0X : SD_DM0Y);
+            const T dnP = D[2] * P[0] + D[5] * P[1] + D[8] * P[2];
+            const T dmx = ((D[0] * P[0] + D[3] * P[1] + D[6] * P[2]) - mx * dnP) * is;
+            const T dmy = ((D[1] * P[0] + D[4] * P[1] + D[7] * P[2]) - my * dnP) * is;
+            const T dx = dmx - dm0[0], dy = dmy - dm0[1];
             Ju[OI + 10 + k] = ux * dx + uy * dy + fx * dm0[0] + skew * dm0[1];
             Jv[OI + 10 + k] = vx * dx + vy * dy + fy * dm0[1];
         }
     }
-    (void)PI;
 }
 
 // ---- Huber (ceres::HuberLoss + Corrector with rho'' <= 0): weight = rho'(s), rho(s) ------------

@@ -306,6 +306,18 @@ class ReprojHandle:
         capi.check(self.lib, self.lib.cba_reproj_eval_fetch(self.h, dptr(r), dptr(J)))
         return r, J
 
+    def set_scalar(self, scalar: int):
+        """0 = fp64 per-observation arithmetic (default), 1 = fp32 (accumulators stay fp64)."""
+        capi.check(self.lib, self.lib.cba_reproj_set_scalar(self.h, int(scalar)))
+
+    def eval_fetch_f32(self):
+        n, p = self.n_obs, self.local_columns
+        r = np.zeros(2 * n, dtype=np.float32)
+        J = np.zeros((2 * n, p), dtype=np.float32)
+        capi.check(self.lib, self.lib.cba_reproj_eval_fetch_f32(self.h, r.ctypes.data_as(C.POINTER(C.c_float)),
+                                                                J.ctypes.data_as(C.POINTER(C.c_float))))
+        return r, J
+
     def eval_timed(self, warmup: int, iters: int) -> float:
         ms = C.c_double(0.0)
         capi.check(self.lib, self.lib.cba_reproj_eval_timed(self.h, int(warmup), int(iters), C.byref(ms)))

@@ -174,6 +174,15 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J);
  * returns the average milliseconds per evaluation of the dominant kernel region. */
 cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_eval);
 
+/* Arithmetic type of the per-observation kernels (BASELINE config 5's fp32-vs-fp64 study): 0 = fp64
+ * (default), 1 = fp32: observations and per-block constants are rounded to fp32 once, the residual and
+ * Jacobian rows are evaluated in fp32, and EVERY accumulator (J^T J, J^T r, |r|^2), the Schur step and the
+ * LM stay fp64.  Affects cba_reproj_eval / _eval_timed / _cost / _block_normal_eq / _solve / _covariance.
+ * With fp32 the Mode A output is float: fetch it with cba_reproj_eval_fetch_f32 (same layout as
+ * cba_reproj_eval_fetch). */
+cba_status cba_reproj_set_scalar(cba_reproj* h, int32_t scalar);
+cba_status cba_reproj_eval_fetch_f32(cba_reproj* h, float* r, float* J);
+
 /* Cost 1/2 sum rho(|r_b|^2) at the current parameters (residual-only pass). */
 cba_status cba_reproj_cost(cba_reproj* h, double huber_delta, double* cost);
 
