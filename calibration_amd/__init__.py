@@ -24,6 +24,9 @@ from .optim import (  # noqa: F401
     optimize_extrinsics,
     optimize_handeye,
     optimize_intrinsics,
+    optimize_planar_pose,
+    optimize_planar_pose_batch,
+    PlanarPoseOptions,
 )
 
 __version__ = "0.1.0"

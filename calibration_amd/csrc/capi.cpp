@@ -580,4 +580,23 @@ cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, c
     });
 }
 
+cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                          const double* u, const double* v, const double* kmtx5, int32_t num_radial,
+                                          double* pose7, const cba_options* opts, cba_summary* summaries, double* distortion,
+                                          double* reprojection_error, double* cov36) {
+    return guarded([&] {
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        planar_pose_batch(n_views, view_offset, X, Y, u, v, kmtx5, num_radial, pose7, opts, summaries, distortion, reprojection_error,
+                          cov36, 0);
+    });
+}
+
+cba_status cba_optimize_planar_pose(int32_t n, const double* X, const double* Y, const double* u, const double* v,
+                                    const double* kmtx5, int32_t num_radial, double* pose7, const cba_options* opts,
+                                    cba_summary* summary, double* distortion, double* reprojection_error, double* cov36) {
+    const int64_t off[2] = {0, n};
+    return cba_optimize_planar_pose_batch(1, off, X, Y, u, v, kmtx5, num_radial, pose7, opts, summary, distortion, reprojection_error,
+                                          cov36);
+}
+
 }  // extern "C"

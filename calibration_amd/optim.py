@@ -104,6 +104,20 @@ class BundleResult:  # bundle.h:39-45
 
 
 @dataclass
+class PlanarPoseOptions:  # planarpose.h:12-15
+    core: OptimOptions = field(default_factory=OptimOptions)
+    num_radial: int = 2
+
+
+@dataclass
+class PlanarPoseResult:  # planarpose.h:17-22
+    core: OptimResult
+    pose: np.ndarray
+    distortion: np.ndarray
+    reprojection_error: float = 0.0
+
+
+@dataclass
 class HandeyeResult:  # handeye.h:16-19
     core: OptimResult
     g_se3_c: np.ndarray
@@ -445,3 +459,37 @@ def optimize_handeye(base_se3_gripper, camera_se3_target, init_gripper_se3_ref, 
     capi.check(lib, lib.cba_optimize_handeye(n, dptr(bg), dptr(ct), dptr(x), C.byref(copts), C.byref(s),
                                              dptr(cov) if options.compute_covariance else dptr(None)))
     return HandeyeResult(result_core(s, cov if options.compute_covariance else None), pose_to_matrix(x))
+
+
+def optimize_planar_pose_batch(views, intrinsics, init_poses, opts: Optional[PlanarPoseOptions] = None) -> List[PlanarPoseResult]:
+    """Batched optimize_planar_pose: every view is an independent 6-parameter variable-projection solve, all run
+    in ONE kernel launch (one GPU thread per view).  intrinsics = [fx, fy, cx, cy, skew]."""
+    opts = opts or PlanarPoseOptions()
+    lib = capi.load_library()
+    nv = len(views)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views]
+    off = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    K = np.ascontiguousarray(np.asarray(intrinsics, dtype=np.float64).reshape(5))
+    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_poses])) if nv else np.zeros((0, 7))
+    m = int(opts.num_radial) + 2
+    summ = (CbaSummary * max(nv, 1))()
+    dist = np.zeros((max(nv, 1), m))
+    rms = np.zeros(max(nv, 1))
+    cov = np.zeros((max(nv, 1), 36))
+    copts = to_cba_options(opts.core)
+    capi.check(lib, lib.cba_optimize_planar_pose_batch(nv, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), int(opts.num_radial),
+                                                       dptr(poses), C.byref(copts), summ, dptr(dist), dptr(rms),
+                                                       dptr(cov) if opts.core.compute_covariance else dptr(None)))
+    out = []
+    for i in range(nv):
+        c = cov[i].reshape(6, 6).copy() if opts.core.compute_covariance and np.any(cov[i]) else None
+        out.append(PlanarPoseResult(result_core(summ[i], c), pose_to_matrix(poses[i]), dist[i].copy(), float(rms[i])))
+    return out
+
+
+def optimize_planar_pose(view, intrinsics, init_pose, opts: Optional[PlanarPoseOptions] = None) -> PlanarPoseResult:
+    """optimize_planar_pose (planarpose.h:24-26, planarpose.cpp:84-127)."""
+    return optimize_planar_pose_batch([view], intrinsics, [init_pose], opts)[0]

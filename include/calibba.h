@@ -19,6 +19,8 @@
  *                               (src/estimation/optim/bundle.cpp:147-170)
  *   cba_optimize_handeye        include/calib/estimation/optim/handeye.h:40-43
  *                               (src/estimation/optim/handeye.cpp:60-78)
+ *   cba_optimize_planar_pose    include/calib/estimation/optim/planarpose.h:24-26
+ *                               (src/estimation/optim/planarpose.cpp:84-127)
  *   cba_reproj_* (handle API)   the ceres::Problem the reference builds and solves inside those
  *                               functions (intrinsics.cpp:63-90, extrinsics.cpp:86-160,
  *                               bundle.cpp:83-133, detail/ceresutils.h:27-43,69-126); exposed so
@@ -238,6 +240,23 @@ cba_status cba_optimize_bundle(int32_t camera_model, int32_t n_cams, int32_t n_b
 cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
                                 double* g_T_c /*[7] in/out*/, const cba_options* opts, cba_summary* summary,
                                 double* cov);
+
+/* optimize_planar_pose (include/calib/estimation/optim/planarpose.h:24-26, src/estimation/optim/planarpose.cpp:84-127):
+ * pose refinement of ONE planar view for fixed K = [fx, fy, cx, cy, skew] by variable projection over the
+ * Brown-Conrady coefficients (num_radial radial + 2 tangential, PlanarPoseOptions::num_radial default 2).
+ * pose7 in/out; distortion [num_radial + 2] = fitted coefficients; reprojection_error = sqrt(ssr / 2N);
+ * cov36 = 6x6 covariance of [angle-axis, t] scaled by ssr / max(1, 2N - 6) (zeros if rank deficient), may be NULL.
+ * Fewer than 8 observations: the reference's functor fails to evaluate and Ceres reports FAILURE
+ * (success = false), not an exception; same here.
+ * The _batch form solves n_views independent views in one launch (one GPU thread per view); arrays are
+ * per view: pose7 [n_views][7], summaries [n_views], distortion [n_views][num_radial + 2], etc. */
+cba_status cba_optimize_planar_pose(int32_t n, const double* X, const double* Y, const double* u, const double* v,
+                                    const double* kmtx5, int32_t num_radial, double* pose7, const cba_options* opts,
+                                    cba_summary* summary, double* distortion, double* reprojection_error, double* cov36);
+cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                          const double* u, const double* v, const double* kmtx5, int32_t num_radial,
+                                          double* pose7, const cba_options* opts, cba_summary* summaries, double* distortion,
+                                          double* reprojection_error, double* cov36);
 
 #ifdef __cplusplus
 }

@@ -360,6 +360,53 @@ double orc_reproj_bench_eval(const cba_reproj_problem* d, int b0, int b1, int th
     return secs;
 }
 
+// ---- planar pose (variable projection) ---------------------------------------------------------
+// residual (2N) and Jacobian (2N x 6, row-major) of PlanarPoseVPResidual at pose6 = [angle-axis, t]
+int orc_planar_vp_eval(int n, const double* X, const double* Y, const double* u, const double* v, const double* kmtx5,
+                       int num_radial, const double* pose6, double* r, double* J, double* alpha) {
+    return guarded([&] {
+        ViewData vd; vd.n = n; vd.X = X; vd.Y = Y; vd.u = u; vd.v = v;
+        PlanarPoseVPBlock blk(vd, kmtx5, num_radial);
+        const double* x[1] = {pose6};
+        double* Jp[1] = {J};
+        blk.evaluate(x, r, J ? Jp : nullptr);
+        if (alpha) { std::vector<double> rr(2 * n); blk.residuals<double>(pose6, rr.data(), alpha); }
+    });
+}
+
+// optimize_planar_pose core (planarpose.cpp:84-127) with pose6 in/out:
+//   rms = sqrt(ssr / 2N), cov66 = (J~^T J~)^-1 * ssr / max(1, 2N - 6)  (ceresutils.h:117-123), distortion = alpha
+int orc_planar_pose_solve(int n, const double* X, const double* Y, const double* u, const double* v, const double* kmtx5,
+                          int num_radial, double* pose6, const cba_options* o, cba_summary* out, double* distortion,
+                          double* rms, double* cov66) {
+    return guarded([&] {
+        ViewData vd; vd.n = n; vd.X = X; vd.Y = Y; vd.u = u; vd.v = v;
+        Problem p;
+        const int id = p.add_param(pose6, 6);
+        auto rb = std::make_unique<PlanarPoseVPBlock>(vd, kmtx5, num_radial);
+        const PlanarPoseVPBlock* raw = rb.get();
+        rb->pb = {id};
+        p.residuals.push_back(std::move(rb));
+        LMSummary s;
+        const auto t0 = std::chrono::steady_clock::now();
+        p.solve(to_lm(*o, 1), &s);
+        fill_summary(s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        std::vector<double> r(2 * n), al(num_radial + 2);
+        raw->residuals<double>(pose6, r.data(), al.data());
+        double ssr = 0;
+        for (double e : r) ssr += e * e;
+        if (rms) *rms = std::sqrt(ssr / (2 * n));
+        if (distortion) for (int k = 0; k < num_radial + 2; ++k) distortion[k] = al[k];
+        if (cov66) {
+            std::vector<double> c; int dim = 0;
+            if (p.covariance(to_lm(*o, 1), {id}, &c, &dim)) {
+                const double vf = ssr / std::max(1, 2 * n - 6);
+                for (int k = 0; k < 36; ++k) cov66[k] = c[k] * vf;
+            } else std::memset(cov66, 0, sizeof(double) * 36);
+        }
+    });
+}
+
 // ---- AX = XB ---------------------------------------------------------------------------------
 // residuals (6) + ambient Jacobians (6x4, 6x3) + tangent Jacobian (6x6) for one pair
 void orc_axxb_eval(const double* q, const double* t, const double* RA, const double* RB, const double* tA,

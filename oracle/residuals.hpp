@@ -110,6 +110,117 @@ struct AxXbBlock final : ResidualBlock {
     }
 };
 
+// ceres::AngleAxisRotatePoint (third-party ceres/rotation.h, restated): Rodrigues for theta^2 > eps,
+// first-order Taylor otherwise.
+template <typename T>
+inline void angle_axis_rotate_point(const T* aa, const T* pt, T* out) {
+    const T theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    if (theta2 > T(2.220446049250313e-16)) {
+        const T theta = sqrt(theta2);
+        const T c = cos(theta), s = sin(theta), ti = T(1.0) / theta;
+        const T w[3] = {aa[0] * ti, aa[1] * ti, aa[2] * ti};
+        const T wxp[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+        const T tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (T(1.0) - c);
+        for (int i = 0; i < 3; ++i) out[i] = pt[i] * c + wxp[i] * s + w[i] * tmp;
+    } else {
+        const T wxp[3] = {aa[1] * pt[2] - aa[2] * pt[1], aa[2] * pt[0] - aa[0] * pt[2], aa[0] * pt[1] - aa[1] * pt[0]};
+        for (int i = 0; i < 3; ++i) out[i] = pt[i] + wxp[i];
+    }
+}
+
+// PlanarPoseVPResidual::operator(), src/estimation/optim/planarpose.cpp:39-57:
+//   to_observation (observationutils.h:97-113) -> fit_distortion_full (models/distortion.h:229-295)
+//   -> residual = A alpha - b with alpha = argmin |A alpha - b|.
+// The reference solves the least squares with a thin JacobiSVD on Jets (distortion.h:290-294); for a full
+// column rank A the minimiser is unique, and it is computed here from the normal equations (Cholesky on
+// Jets), which differentiates to the same Golub-Pereyra derivative.
+struct PlanarPoseVPBlock final : ResidualBlock {
+    ViewData view;
+    double K[5];  // fx fy cx cy skew
+    int num_radial;
+    PlanarPoseVPBlock(const ViewData& v, const double* kmtx5, int nr) : view(v), num_radial(nr) {
+        for (int i = 0; i < 5; ++i) K[i] = kmtx5[i];
+        if (v.n < 8) throw std::invalid_argument("fit_distortion_full needs at least 8 observations");  // distortion.h:236-239
+        nres = 2 * v.n;
+    }
+    template <typename T>
+    void residuals(const T* pose6, T* r, T* alpha_out) const {
+        const int m = num_radial + 2, N = view.n;
+        const T fx(K[0]), fy(K[1]), cx(K[2]), cy(K[3]), skew(K[4]);
+        std::vector<T> A(static_cast<size_t>(2 * N) * m), b(2 * N);
+        for (int i = 0; i < N; ++i) {
+            const T pt[3] = {T(view.X[i]), T(view.Y[i]), T(0.0)};
+            T pc[3];
+            angle_axis_rotate_point(pose6, pt, pc);
+            for (int k = 0; k < 3; ++k) pc[k] = pc[k] + pose6[3 + k];
+            const T iz = T(1.0) / pc[2];
+            const T x = pc[0] * iz, y = pc[1] * iz;
+            const T r2 = x * x + y * y;
+            T* Au = &A[static_cast<size_t>(2 * i) * m];
+            T* Av = &A[static_cast<size_t>(2 * i + 1) * m];
+            T rpow = r2;
+            for (int j = 0; j < num_radial; ++j) {
+                Au[j] = fx * x * rpow + skew * y * rpow;
+                Av[j] = fy * y * rpow;
+                rpow = rpow * r2;
+            }
+            Au[num_radial] = fx * (T(2.0) * x * y) + skew * (r2 + T(2.0) * y * y);
+            Au[num_radial + 1] = fx * (r2 + T(2.0) * x * x) + skew * (T(2.0) * x * y);
+            Av[num_radial] = fy * (r2 + T(2.0) * y * y);
+            Av[num_radial + 1] = fy * (T(2.0) * x * y);
+            b[2 * i] = T(view.u[i]) - (fx * x + skew * y + cx);
+            b[2 * i + 1] = T(view.v[i]) - (fy * y + cy);
+        }
+        // normal equations + Cholesky
+        std::vector<T> M(static_cast<size_t>(m) * m, T(0.0)), rhs(m, T(0.0)), L(static_cast<size_t>(m) * m, T(0.0)), al(m);
+        for (int row = 0; row < 2 * N; ++row)
+            for (int a = 0; a < m; ++a) {
+                rhs[a] = rhs[a] + A[static_cast<size_t>(row) * m + a] * b[row];
+                for (int c = 0; c <= a; ++c) M[a * m + c] = M[a * m + c] + A[static_cast<size_t>(row) * m + a] * A[static_cast<size_t>(row) * m + c];
+            }
+        for (int j = 0; j < m; ++j) {
+            T d = M[j * m + j];
+            for (int k = 0; k < j; ++k) d = d - L[j * m + k] * L[j * m + k];
+            d = sqrt(d);
+            L[j * m + j] = d;
+            for (int i = j + 1; i < m; ++i) {
+                T sacc = M[i * m + j];
+                for (int k = 0; k < j; ++k) sacc = sacc - L[i * m + k] * L[j * m + k];
+                L[i * m + j] = sacc / d;
+            }
+        }
+        for (int i = 0; i < m; ++i) {
+            T sacc = rhs[i];
+            for (int k = 0; k < i; ++k) sacc = sacc - L[i * m + k] * al[k];
+            al[i] = sacc / L[i * m + i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+            T sacc = al[i];
+            for (int k = i + 1; k < m; ++k) sacc = sacc - L[k * m + i] * al[k];
+            al[i] = sacc / L[i * m + i];
+        }
+        for (int row = 0; row < 2 * N; ++row) {
+            T sacc = -b[row];
+            for (int a = 0; a < m; ++a) sacc = sacc + A[static_cast<size_t>(row) * m + a] * al[a];
+            r[row] = sacc;
+        }
+        if (alpha_out)
+            for (int a = 0; a < m; ++a) alpha_out[a] = al[a];
+    }
+    void evaluate(const double* const* x, double* r, double** J) const override {
+        if (!J) { residuals<double>(x[0], r, nullptr); return; }
+        using JT = Jet<6>;
+        JT p[6];
+        for (int k = 0; k < 6; ++k) p[k] = JT(x[0][k], k);
+        std::vector<JT> rj(nres);
+        residuals<JT>(p, rj.data(), nullptr);
+        for (int i = 0; i < nres; ++i) {
+            r[i] = rj[i].a;
+            if (J[0]) for (int k = 0; k < 6; ++k) J[0][static_cast<size_t>(i) * 6 + k] = rj[i].v[k];
+        }
+    }
+};
+
 inline std::unique_ptr<ResidualBlock> make_reproj_block(int chain, int model, const ViewData& v,
                                                         const double* bTg12) {
     auto fill = [&](auto* blk) {

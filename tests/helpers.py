@@ -33,6 +33,10 @@ def load_oracle():
     o.orc_axxb_eval.argtypes = [c_double_p] * 10
     o.orc_axxb_eval.restype = None
     o.orc_axxb_solve.argtypes = [C.c_int, c_double_p, c_double_p, PO, PS, c_double_p]
+    o.orc_planar_vp_eval.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p,
+                                     c_double_p, c_double_p]
+    o.orc_planar_pose_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, PO, PS,
+                                        c_double_p, c_double_p, c_double_p]
     o.orc_quat_to_rotmat.argtypes = [c_double_p, c_double_p]
     o.orc_rotmat_to_quat.argtypes = [c_double_p, c_double_p]
     o.orc_quat_plus.argtypes = [c_double_p, c_double_p, c_double_p]
@@ -47,6 +51,12 @@ def load_hostmath():
     h.hm_reproj_covariance_dim.argtypes = [PP]
     h.hm_reproj_covariance_dim.restype = C.c_int64
     h.hm_reproj_covariance.argtypes = [PP, PO, c_double_p]
+    h.hm_planar_vp_eval.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p,
+                                    c_double_p, c_double_p, c_double_p, c_double_p]
+    h.hm_planar_pose_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, PO, PS,
+                                       c_double_p, c_double_p, c_double_p]
+    h.hm_quat_to_angle_axis.argtypes = [c_double_p, c_double_p]
+    h.hm_angle_axis_to_quat.argtypes = [c_double_p, c_double_p]
     h.hm_handeye_last_error.restype = C.c_char_p
     h.hm_axxb_eval.argtypes = [c_double_p] * 8
     h.hm_axxb_eval.restype = None
@@ -194,3 +204,38 @@ def handeye_scene(n_poses=18, seed=2024, noise_rot_deg=0.0, noise_trans=0.0):
     X0[:3, :3] = axis_angle_to_R(rng.rand_unit_axis(), np.deg2rad(2.0)) @ X0[:3, :3]
     X0[:3, 3] += [0.01, -0.005, 0.004]
     return seq, cTt, X, X0
+
+
+# ---- planar pose (planarpose_test.cpp:15-34, 96-211) -----------------------------------------------
+PLANAR_K = np.array([1000.0, 1000.0, 500.0, 500.0, 0.0])
+
+
+def planar_pose_scene(distort=False, noise=0.0, seed=0):
+    """create_synthetic_planar_data: 6x6 grid (i, j in -5..5 step 2) * 0.1 m, pose rot 0.1 rad about (1,1,1),
+    t = (0.1, 0.2, 2.0); optional Brown-Conrady coeffs (0.1, 0) = [p1, p2] as in the reference test."""
+    from calibration_amd import synth
+    from calibration_amd.geometry import make_pose
+
+    true = make_pose([0.1, 0.2, 2.0], [1, 1, 1], 0.1)
+    init = make_pose([0.19, 0.23, 2.1], [1, 1, 1], 0.12)
+    g = np.array([[i * 0.1, j * 0.1] for i in range(-5, 6, 2) for j in range(-5, 6, 2)])
+    cam = np.concatenate([PLANAR_K, [0, 0, 0, 0.1 if distort else 0.0, 0.0]])
+    view = synth.render_view(cam, true, g, cull=False)
+    if noise > 0:
+        view[:, 2:] += np.random.default_rng(seed).normal(0, noise, (len(view), 2))
+    return view, true, init
+
+
+def pose6_of(T):
+    """[ceres::RotationMatrixToAngleAxis(R), t]"""
+    from calibration_amd.geometry import pose_from_matrix
+
+    q = pose_from_matrix(T)[:4]
+    s2 = float(q[1:] @ q[1:])
+    if s2 > 0:
+        st = np.sqrt(s2)
+        two = 2.0 * (np.arctan2(-st, -q[0]) if q[0] < 0 else np.arctan2(st, q[0]))
+        aa = q[1:] * (two / st)
+    else:
+        aa = q[1:] * 2.0
+    return np.ascontiguousarray(np.concatenate([aa, np.asarray(T)[:3, 3]]))

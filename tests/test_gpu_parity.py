@@ -335,3 +335,47 @@ def test_fp32_lm_deviation_from_fp64(gpu_lib, oracle, model):
     assert d[:4].max() <= 5e-2, d
     assert d[5] <= 1e-3 and d[6] <= 1e-2 and d[7] <= 5e-2 and d[8:10].max() <= 1e-4, d
     print("fp32-vs-fp64 LM parameter deviation:", d)
+
+
+# ---- planar pose by variable projection on the GPU (a5) ----------------------------------------------
+def test_reference_kat_planar_pose_on_gpu(gpu_lib):
+    """planarpose_test.cpp:96-146 and :148-211 through the mirror API."""
+    view, true, init = helpers.planar_pose_scene()
+    res = optim.optimize_planar_pose(view, helpers.PLANAR_K, init, optim.PlanarPoseOptions(num_radial=0))
+    assert res.reprojection_error < 1e-3
+    assert np.linalg.norm(res.pose[:3, :3] - true[:3, :3]) <= 1e-1 * np.linalg.norm(true[:3, :3])
+    sc = true[2, 3] / res.pose[2, 3]
+    assert np.linalg.norm(true[:3, 3] - sc * res.pose[:3, 3]) < 0.1
+    view, true, init = helpers.planar_pose_scene(distort=True)
+    res = optim.optimize_planar_pose(view, helpers.PLANAR_K, init, optim.PlanarPoseOptions(num_radial=1))
+    assert res.reprojection_error < 1e-2
+    assert np.linalg.norm(res.pose[:3, :3] - true[:3, :3]) <= 1e-1 * np.linalg.norm(true[:3, :3])
+    assert len(res.distortion) == 3 and abs(res.distortion[0] - 0.1) <= 0.2
+
+
+def test_planar_pose_batch_matches_oracle(gpu_lib, oracle):
+    from calibration_amd.geometry import pose_from_matrix
+
+    rng = np.random.default_rng(4)
+    cam = synth.camera_gt(0)
+    K = np.ascontiguousarray(cam[:5])
+    views, inits = [], []
+    for i in range(37):
+        T = synth.random_view_poses(1, rng, dist=1.5)[0]
+        grid = synth.make_target_grid(5 + i % 4, 6 + i % 3, 0.05)
+        views.append(synth.render_view(cam, T, grid, noise_px=0.2, rng=rng))
+        inits.append(synth.perturb_pose(T, rng, 1.5, 0.02))
+    for nr in (0, 2):
+        out = optim.optimize_planar_pose_batch(views, K, inits, optim.PlanarPoseOptions(num_radial=nr))
+        o = options()
+        for i, (vw, T0) in enumerate(zip(views, inits)):
+            X, Y, u, v = (np.ascontiguousarray(vw[:, k]) for k in range(4))
+            p, s, d, rms, cov = helpers.pose6_of(T0), capi.CbaSummary(), np.zeros(nr + 2), C.c_double(), np.zeros((6, 6))
+            assert oracle.orc_planar_pose_solve(len(vw), capi.dptr(X), capi.dptr(Y), capi.dptr(u), capi.dptr(v), capi.dptr(K), nr, capi.dptr(p),
+                                                C.byref(o), C.byref(s), capi.dptr(d), C.byref(rms), capi.dptr(cov)) == 0
+            r = out[i]
+            assert r.core.success == bool(s.success) and abs(r.core.iterations - s.iterations) <= 1
+            assert abs(r.reprojection_error - rms.value) <= 1e-9
+            assert np.abs(helpers.pose6_of(r.pose) - p).max() <= 1e-8
+            assert np.abs(r.distortion - d).max() <= 1e-7
+            assert r.core.covariance is not None and np.abs(r.core.covariance - cov).max() <= 1e-6 * np.abs(cov).max()

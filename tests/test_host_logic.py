@@ -285,3 +285,58 @@ def test_handeye_degenerate_motion_is_runtime_error(hostmath):
     o = options()
     assert hostmath.hm_handeye_solve(5, dptr(p), dptr(p.copy()), dptr(x), C.byref(o), C.byref(s), dptr(None)) == capi.CBA_ERR_RUNTIME
     assert b"No valid motion pairs" in hostmath.hm_handeye_last_error()
+
+
+# ---- planar pose by variable projection (a5) ---------------------------------------------------------
+@pytest.mark.parametrize("nr", [0, 1, 2, 3])
+def test_vp_analytic_jacobian_equals_jets_through_the_ls_solve(oracle, hostmath, nr):
+    view, _, init = helpers.planar_pose_scene(distort=True, noise=0.1)
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    K = helpers.PLANAR_K.copy()
+    K[4] = 0.3
+    p0 = helpers.pose6_of(init)
+    m, n = nr + 2, len(view)
+    r0, J0, a0 = np.zeros(2 * n), np.zeros((2 * n, 6)), np.zeros(m)
+    assert oracle.orc_planar_vp_eval(n, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), nr, dptr(p0), dptr(r0), dptr(J0), dptr(a0)) == 0
+    r1, J1, a1, H, g = np.zeros(2 * n), np.zeros((2 * n, 6)), np.zeros(m), np.zeros((6, 6)), np.zeros(6)
+    assert hostmath.hm_planar_vp_eval(n, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), nr, dptr(p0), dptr(r1), dptr(J1), dptr(a1), dptr(H),
+                                      dptr(g)) == 0
+    assert np.abs(r0 - r1).max() <= 1e-10
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-10
+    assert np.abs(a0 - a1).max() <= 1e-10
+    assert np.abs(H - J1.T @ J1).max() <= 1e-12 * np.abs(H).max() and np.abs(g - J1.T @ r1).max() <= 1e-10 * max(1.0, np.abs(g).max())
+
+
+@pytest.mark.parametrize("nr,distort,noise", [(0, False, 0.0), (1, True, 0.0), (2, True, 0.2), (3, True, 0.2)])
+def test_vp_per_view_lm_matches_oracle_and_reference_kat(oracle, hostmath, nr, distort, noise):
+    """planarpose_test.cpp:96-146 (num_radial 0, RMS < 1e-3) and :148-211 (num_radial 1, RMS < 1e-2, loose pose)."""
+    view, true, init = helpers.planar_pose_scene(distort=distort, noise=noise)
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    K, n, m = helpers.PLANAR_K, len(view), nr + 2
+    o = options()
+    res = {}
+    for name, fn in (("oracle", oracle.orc_planar_pose_solve), ("product", hostmath.hm_planar_pose_solve)):
+        p, s, d, rms, cov = helpers.pose6_of(init), CbaSummary(), np.zeros(m), C.c_double(), np.zeros((6, 6))
+        assert fn(n, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), nr, dptr(p), C.byref(o), C.byref(s), dptr(d), C.byref(rms), dptr(cov)) == 0
+        res[name] = (p, s, d, rms.value, cov)
+    (pa, sa, da, ra, ca), (pb, sb, db, rb, cb) = res["oracle"], res["product"]
+    assert sa.termination == sb.termination and abs(sa.iterations - sb.iterations) <= 1
+    assert np.abs(pa - pb).max() <= 1e-9 and np.abs(da - db).max() <= 1e-8 and abs(ra - rb) <= 1e-9
+    if noise > 0:  # (noise-free: ssr is rounding noise ~1e-25, so the ssr/dof-scaled covariance is too)
+        assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
+    if noise == 0.0:
+        assert rb < (1e-3 if nr == 0 else 1e-2)
+        assert np.linalg.eigvalsh(cb).min() > 0 or rb < 1e-9  # planarpose_test.cpp:145 (covariance PD)
+    if distort and nr == 1:
+        assert abs(db[0] - 0.1) <= 0.2  # planarpose_test.cpp:210 (lenient by design)
+
+
+def test_vp_too_few_points_is_failure_not_exception(hostmath):
+    view, _, init = helpers.planar_pose_scene()
+    view = view[:7]
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    p, s, d, rms = helpers.pose6_of(init), CbaSummary(), np.zeros(2), C.c_double()
+    o = options()
+    assert hostmath.hm_planar_pose_solve(7, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(helpers.PLANAR_K), 0, dptr(p), C.byref(o), C.byref(s),
+                                         dptr(d), C.byref(rms), dptr(None)) == 0
+    assert s.termination == capi.TERM_FAILURE and not s.success
