@@ -11,6 +11,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 
 #include "engine.hpp"
 #include "structure.hpp"
@@ -105,18 +106,66 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     CBA_HIP(hipEventCreate(&e.ev0));
     CBA_HIP(hipEventCreate(&e.ev1));
 
-    // ---- observations: padded SoA --------------------------------------------------------------
+    // ---- observations: padded SoA; X, Y deduplicated across blocks ------------------------------------
     {
-        std::vector<double> buf(static_cast<size_t>(e.ld));
-        const double* src[4] = {d.X, d.Y, d.u, d.v};
-        DevBuf<double>* dst[4] = {&e.X, &e.Y, &e.u, &e.v};
-        for (int a = 0; a < 4; ++a) {
-            std::fill(buf.begin(), buf.end(), 0.0);
+        // residual blocks whose (X, Y) lists are bitwise identical share one device copy
+        e.xy_offset.assign(d.n_blocks, 0);
+        std::unordered_map<uint64_t, std::vector<int>> seen;
+        std::vector<int> owner(d.n_blocks, -1);
+        int64_t xy_pad = 0;
+        for (int b = 0; b < d.n_blocks; ++b) {
+            const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
+            const double* bx = d.X + e.blk_offset[b];
+            const double* by = d.Y + e.blk_offset[b];
+            uint64_t hsh = 1469598103934665603ULL ^ static_cast<uint64_t>(n);
+            auto mix = [&](const double* p) {
+                for (int64_t i = 0; i < n; ++i) {
+                    uint64_t w;
+                    std::memcpy(&w, p + i, 8);
+                    hsh = (hsh ^ w) * 1099511628211ULL;
+                    hsh ^= hsh >> 29;
+                }
+            };
+            mix(bx); mix(by);
+            int found = -1;
+            for (int cand : seen[hsh]) {
+                const int64_t nc = e.blk_offset[cand + 1] - e.blk_offset[cand];
+                if (nc == n && std::memcmp(d.X + e.blk_offset[cand], bx, sizeof(double) * n) == 0 &&
+                    std::memcmp(d.Y + e.blk_offset[cand], by, sizeof(double) * n) == 0) { found = cand; break; }
+            }
+            if (found >= 0) {
+                e.xy_offset[b] = e.xy_offset[found];
+            } else {
+                seen[hsh].push_back(b);
+                owner[b] = b;
+                e.xy_offset[b] = xy_pad;
+                xy_pad += (n + 1) & ~int64_t(1);
+                ++e.n_xy_unique_blocks;
+            }
+        }
+        e.ld_xy = std::max<int64_t>(256, (xy_pad + 255) & ~int64_t(255));
+        std::vector<double> buf;
+        for (int a = 0; a < 2; ++a) {
+            buf.assign(static_cast<size_t>(e.ld_xy), 0.0);
+            const double* src = a == 0 ? d.X : d.Y;
             for (int b = 0; b < d.n_blocks; ++b)
-                std::memcpy(&buf[e.pad_offset[b]], src[a] + e.blk_offset[b],
+                if (owner[b] == b)
+                    std::memcpy(&buf[e.xy_offset[b]], src + e.blk_offset[b],
+                                sizeof(double) * static_cast<size_t>(e.blk_offset[b + 1] - e.blk_offset[b]));
+            DevBuf<double>& dst = a == 0 ? e.X : e.Y;
+            dst.alloc(e.ld_xy);
+            dst.upload(buf.data(), buf.size(), e.stream);
+            CBA_HIP(hipStreamSynchronize(e.stream));
+        }
+        for (int a = 0; a < 2; ++a) {
+            buf.assign(static_cast<size_t>(e.ld), 0.0);
+            const double* src = a == 0 ? d.u : d.v;
+            for (int b = 0; b < d.n_blocks; ++b)
+                std::memcpy(&buf[e.pad_offset[b]], src + e.blk_offset[b],
                             sizeof(double) * static_cast<size_t>(e.blk_offset[b + 1] - e.blk_offset[b]));
-            dst[a]->alloc(e.ld);
-            dst[a]->upload(buf.data(), buf.size(), e.stream);
+            DevBuf<double>& dst = a == 0 ? e.u : e.v;
+            dst.alloc(e.ld);
+            dst.upload(buf.data(), buf.size(), e.stream);
             CBA_HIP(hipStreamSynchronize(e.stream));
         }
     }
@@ -128,10 +177,10 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
             const int64_t np = (n + 1) & ~int64_t(1);
             for (int64_t s = 0; s < np; s += TILE_A)
-                ta.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_A, np - s)), e.pad_offset[b] + s});
+                ta.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_A, np - s)), e.pad_offset[b] + s, e.xy_offset[b] + s, 0});
             e.blk_tile_off[b] = static_cast<int64_t>(tb.size());
             for (int64_t s = 0; s < n; s += TILE_B)
-                tb.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_B, n - s)), e.pad_offset[b] + s});
+                tb.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_B, n - s)), e.pad_offset[b] + s, e.xy_offset[b] + s, 0});
         }
         e.blk_tile_off[d.n_blocks] = static_cast<int64_t>(tb.size());
         e.n_tilesA = static_cast<int64_t>(ta.size());

@@ -1,9 +1,13 @@
 // engine.hpp — internal state behind the opaque cba_reproj handle.
 //
 // HBM layout (all fp64, SoA, one allocation per array):
-//   X, Y, u, v        [ld]          observations; every residual block starts at an EVEN padded index
+//   u, v              [ld]          pixel observations; every residual block starts at an EVEN padded index
 //                                    (so a lane's two observations are one 16-byte load/store) and ld is
 //                                    the padded total rounded up to 256 elements
+//   X, Y              [ld_xy]       target-plane points, DEDUPLICATED: residual blocks whose object_xy lists are
+//                                    bitwise identical (the usual case: every view sees the same physical
+//                                    target) share one copy, so the per-observation HBM read drops from 32 B
+//                                    towards 16 B and the shared copy stays L2 / Infinity-Cache resident
 //   J (Mode A output) [n_tilesA][2 + 2P][128]  tile-blocked: for every 128-observation tile one contiguous
 //                                    (2+2P) KiB region = u/v residual rows, then the P Jacobian columns of
 //                                    the u row, then of the v row (streams like a fill; +6 % over whole-array
@@ -68,10 +72,12 @@ struct DevBuf {
     void zero(hipStream_t s) { CBA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
 
-struct Tile {       // 16 bytes, read with one scalar load per wave
-    int32_t blk;    // residual block
-    int32_t count;  // observations in this tile (Mode A: padded, even; Mode B/R: valid count)
-    int64_t start;  // padded observation index of the tile's first observation
+struct Tile {          // 32 bytes, read with scalar loads (wave-uniform)
+    int32_t blk;       // residual block
+    int32_t count;     // observations in this tile (Mode A: padded, even; Mode B/R: valid count)
+    int64_t start;     // padded observation index of the tile's first observation (u, v, outputs)
+    int64_t xy_start;  // index of the tile's first target point in the DEDUPLICATED X, Y arrays
+    int64_t reserved;
 };
 
 constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
@@ -88,7 +94,8 @@ struct Engine {
     int chain = 0, model = 0;
     int n_blocks = 0, n_cams = 0, n_views = 0;
     int64_t first_view_global = 0;
-    int64_t n_obs = 0, ld = 0;
+    int64_t n_obs = 0, ld = 0, ld_xy = 0;
+    int64_t n_xy_unique_blocks = 0;
     int PI = 10, PL = 16, NACC = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -96,6 +103,7 @@ struct Engine {
 
     std::vector<int64_t> blk_offset;  // unpadded CSR (host)
     std::vector<int64_t> pad_offset;  // padded start of every block (host)
+    std::vector<int64_t> xy_offset;   // start of every block's target points in the deduplicated X, Y arrays (host)
     std::vector<int32_t> blk_cam, blk_view;
     std::vector<int64_t> blk_tile_off;  // Mode B tiles per block CSR (host)
     int64_t n_tilesA = 0, n_tilesB = 0;

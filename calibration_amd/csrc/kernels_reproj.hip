@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, in
             c.x = T(600); c.y = T(610); d.x = T(300); d.y = T(310);
         } else {
             // lanes past the tile's end read the tile's first pair (in bounds, result unused)
-            const int64_t i = tt.start + ((2 * lane < tt.count) ? 2 * lane : 0);
-            a = *reinterpret_cast<const V2*>(X + i);
-            b = *reinterpret_cast<const V2*>(Y + i);
-            c = *reinterpret_cast<const V2*>(u + i);
-            d = *reinterpret_cast<const V2*>(v + i);
+            const int64_t o = (2 * lane < tt.count) ? 2 * lane : 0;
+            a = *reinterpret_cast<const V2*>(X + tt.xy_start + o);
+            b = *reinterpret_cast<const V2*>(Y + tt.xy_start + o);
+            c = *reinterpret_cast<const V2*>(u + tt.start + o);
+            d = *reinterpret_cast<const V2*>(v + tt.start + o);
         }
     };
     load_obs(t, Xv, Yv, uv, vv);
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, i
     for (int k = 0; k < OPL_B; ++k) {
         const int j = lane + 64 * k;
         if (j < t.count) {
-            const int64_t i = t.start + j;
+            const int64_t i = t.start + j, k2 = t.xy_start + j;
             T rr[2];
-            reproj_residual<MODEL, T>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rr);
+            reproj_residual<MODEL, T>(bcp, ip, sp, X[k2], Y[k2], u[i], v[i], rr);
             s += static_cast<double>(rr[0]) * rr[0] + static_cast<double>(rr[1]) * rr[1];
         }
     }
@@ -273,9 +273,9 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
     for (int k = 0; k < OPL_B; ++k) {
         const int j = lane + 64 * k;
         if (j < t.count) {
-            const int64_t i = t.start + j;
+            const int64_t i = t.start + j, k2 = t.xy_start + j;
             T rt[2], Jut[PL], Jvt[PL];
-            reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, X[i], Y[i], u[i], v[i], rt, Jut, Jvt);
+            reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, X[k2], Y[k2], u[i], v[i], rt, Jut, Jvt);
             double rr[2], Ju[PL], Jv[PL];
             rr[0] = rt[0]; rr[1] = rt[1];
 #pragma unroll
@@ -321,12 +321,13 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
 static inline unsigned blocks_for(int64_t n, int per) { return static_cast<unsigned>((n + per - 1) / per); }
 
 void ensure_f32_buffers(Engine& e) {
-    if (e.Xf.n >= static_cast<size_t>(e.ld) && e.bcf.n > 0) return;
+    if (e.uf.n >= static_cast<size_t>(e.ld) && e.bcf.n > 0) return;
     const DevBuf<double>* src[4] = {&e.X, &e.Y, &e.u, &e.v};
     DevBuf<float>* dst[4] = {&e.Xf, &e.Yf, &e.uf, &e.vf};
     for (int a = 0; a < 4; ++a) {
-        dst[a]->alloc(static_cast<size_t>(e.ld));
-        hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(e.ld, 256)), dim3(256), 0, e.stream, e.ld, src[a]->p, dst[a]->p);
+        const int64_t n = a < 2 ? e.ld_xy : e.ld;
+        dst[a]->alloc(static_cast<size_t>(n));
+        hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(n, 256)), dim3(256), 0, e.stream, n, src[a]->p, dst[a]->p);
     }
     e.bcf.alloc(static_cast<size_t>(std::max(1, e.n_blocks)) * BC_SIZE);
     e.sdf.alloc(static_cast<size_t>(e.n_cams) * SD_SIZE);

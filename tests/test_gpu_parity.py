@@ -382,3 +382,31 @@ def test_planar_pose_batch_matches_oracle(gpu_lib, oracle):
             assert np.abs(helpers.pose6_of(r.pose) - p).max() <= 1e-8
             assert np.abs(r.distortion - d).max() <= 1e-7
             assert r.core.covariance is not None and np.abs(r.core.covariance - cov).max() <= 1e-6 * np.abs(cov).max()
+
+
+def test_shared_and_distinct_target_point_lists(gpu_lib, oracle):
+    """X, Y deduplication: views with identical object_xy lists share one device copy, views with different
+    lists (dropped corners, reordered points, another target) do not; results are the same either way."""
+    sc = synth.scene_intrinsics(9, rows=9, cols=14, spacing=0.05, noise_px=0.3)
+    f = sc.flat
+    views = []
+    for b in range(f.n_blocks):
+        lo, hi = f.blk_offset[b], f.blk_offset[b + 1]
+        vw = np.stack([f.X[lo:hi], f.Y[lo:hi], f.u[lo:hi], f.v[lo:hi]], axis=1)
+        if b % 3 == 1:
+            vw = vw[::-1].copy()  # same points, different order
+        if b % 3 == 2:
+            vw = np.delete(vw, [5, 17, 40], axis=0)  # dropped corners
+        views.append(vw)
+    flat = optim.FlatProblem(f.chain, f.model, views, np.zeros(9, np.int32), np.arange(9, dtype=np.int32), f.intr, None, f.view_pose, None)
+    r0, J0 = helpers.oracle_eval(oracle, flat)
+    ref = helpers.oracle_block_normal_eq(oracle, flat)
+    with optim.ReprojHandle(flat) as h:
+        h.eval()
+        r1, J1 = h.eval_fetch()
+        nb = h.block_normal_eq()
+        c = h.cost(1.0)
+    assert np.abs(r0 - r1).max() <= 1e-9
+    assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+    assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
+    assert abs(c - helpers.oracle_cost(oracle, flat)) <= 1e-10 * c
