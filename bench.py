@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="points per view = grid^2")
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lm-timeout", type=float, default=240.0, help="watchdog for the LM section, seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,9 +107,13 @@ def main():
                 "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
-    lm = None
-    if not args.no_lm:
+    # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path
+    # cannot be rehearsed on a 1-GPU box) must not swallow the evals/s line measured above.
+    lm_box = {}
+
+    def run_lm():
         try:
+            torch.cuda.set_device(local_rank)
             if world > 1:
                 try:  # RCCL-native: ncclAllReduce of the packed reduced system on the engine's stream
                     uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
@@ -134,11 +139,22 @@ def main():
             s = h.solve(o)
             barrier()
             lm_s = time.perf_counter() - t1
-            lm = {"wall_s": lm_s, "iterations": int(s.iterations), "success": bool(s.success), "final_cost": float(s.final_cost),
-                  "intr_err_max": float(np.abs(flat.intr - scene.gt_intr).max()), "views_total": world * args.views,
-                  "obs_total": world * n_obs, "allreduce": transport}
+            lm_box["lm"] = {"wall_s": lm_s, "iterations": int(s.iterations), "success": bool(s.success),
+                            "final_cost": float(s.final_cost),
+                            "intr_err_max": float(np.abs(flat.intr - scene.gt_intr).max()), "views_total": world * args.views,
+                            "obs_total": world * n_obs, "allreduce": transport}
         except Exception as ex:  # the evals/s line must still be printed
-            lm = {"error": f"{type(ex).__name__}: {ex}"}
+            lm_box["lm"] = {"error": f"{type(ex).__name__}: {ex}"}
+
+    lm, lm_hung = None, False
+    if not args.no_lm:
+        import threading
+
+        th = threading.Thread(target=run_lm, daemon=True)
+        th.start()
+        th.join(args.lm_timeout)
+        lm_hung = th.is_alive()
+        lm = {"error": f"LM solve did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else lm_box.get("lm")
 
     # ---- CPU baseline: the oracle's autodiff evaluation on a bounded sample, rank 0 only --------------
     cpu = None
@@ -184,7 +200,9 @@ def main():
             "lm": lm,
             "scene_gen_s": t_gen,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if lm_hung:  # a stuck collective cannot be cancelled: leave without touching the GPU again
+        os._exit(0)
     h.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -648,4 +648,23 @@ cba_status cba_optimize_planar_pose(int32_t n, const double* X, const double* Y,
                                           cov36);
 }
 
+cba_status cba_optimize_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                         const double* u, const double* v, double* h9, const cba_options* opts,
+                                         cba_summary* summaries, double* cov64) {
+    return guarded([&] {
+        if (!view_offset || !X || !Y || !u || !v || !h9 || !opts) throw std::invalid_argument("null argument");
+        if (n_views <= 0) throw std::invalid_argument("At least 4 correspondences are required.");
+        for (int i = 0; i < n_views; ++i)  // homography.cpp:146-148, checked before any device work like the reference
+            if (view_offset[i + 1] - view_offset[i] < 4) throw std::invalid_argument("At least 4 correspondences are required.");
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        homography_batch(n_views, view_offset, X, Y, u, v, h9, opts, summaries, cov64, 0);
+    });
+}
+
+cba_status cba_optimize_homography(int32_t n, const double* X, const double* Y, const double* u, const double* v, double* h9,
+                                   const cba_options* opts, cba_summary* summary, double* cov64) {
+    const int64_t off[2] = {0, n};
+    return cba_optimize_homography_batch(1, off, X, Y, u, v, h9, opts, summary, cov64);
+}
+
 }  // extern "C"

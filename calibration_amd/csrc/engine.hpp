@@ -177,6 +177,8 @@ void rccl_destroy(Engine& e);
 void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, int num_radial, double* pose7, const cba_options* o, cba_summary* summaries,
                        double* distortion, double* rms, double* cov, int device);
+void homography_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
+                      double* h9, const cba_options* o, cba_summary* summaries, double* cov64, int device);
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
                    double* cov, int device);
 

@@ -118,6 +118,12 @@ class PlanarPoseResult:  # planarpose.h:17-22
 
 
 @dataclass
+class OptimizeHomographyResult:  # homography.h:12-15
+    core: OptimResult
+    homography: np.ndarray
+
+
+@dataclass
 class HandeyeResult:  # handeye.h:16-19
     core: OptimResult
     g_se3_c: np.ndarray
@@ -493,3 +499,32 @@ def optimize_planar_pose_batch(views, intrinsics, init_poses, opts: Optional[Pla
 def optimize_planar_pose(view, intrinsics, init_pose, opts: Optional[PlanarPoseOptions] = None) -> PlanarPoseResult:
     """optimize_planar_pose (planarpose.h:24-26, planarpose.cpp:84-127)."""
     return optimize_planar_pose_batch([view], intrinsics, [init_pose], opts)[0]
+
+
+def optimize_homography_batch(views, init_hs, options: Optional[OptimOptions] = None) -> List[OptimizeHomographyResult]:
+    """Batched optimize_homography: every view is an independent 8-parameter refinement (one residual block and one
+    Huber loss per correspondence), all views in ONE kernel launch (one wavefront per view)."""
+    options = options or OptimOptions()
+    lib = capi.load_library()
+    nv = len(views)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views]
+    off = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    H = np.ascontiguousarray(np.stack([np.asarray(h, dtype=np.float64).reshape(9) for h in init_hs])) if nv else np.zeros((0, 9))
+    summ = (CbaSummary * max(nv, 1))()
+    cov = np.zeros((max(nv, 1), 64))
+    copts = to_cba_options(options)
+    capi.check(lib, lib.cba_optimize_homography_batch(nv, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(H), C.byref(copts), summ,
+                                                      dptr(cov) if options.compute_covariance else dptr(None)))
+    out = []
+    for i in range(nv):
+        c = cov[i].reshape(8, 8).copy() if options.compute_covariance and np.any(cov[i]) else None
+        out.append(OptimizeHomographyResult(result_core(summ[i], c), H[i].reshape(3, 3).copy()))
+    return out
+
+
+def optimize_homography(data, init_h, options: Optional[OptimOptions] = None) -> OptimizeHomographyResult:
+    """optimize_homography (homography.h:17-18, homography.cpp:144-175); data rows = [x, y, u, v]."""
+    return optimize_homography_batch([data], [init_h], options)[0]

@@ -21,6 +21,8 @@
  *                               (src/estimation/optim/handeye.cpp:60-78)
  *   cba_optimize_planar_pose    include/calib/estimation/optim/planarpose.h:24-26
  *                               (src/estimation/optim/planarpose.cpp:84-127)
+ *   cba_optimize_homography     include/calib/estimation/optim/homography.h:17-18
+ *                               (src/estimation/optim/homography.cpp:144-175)
  *   cba_reproj_* (handle API)   the ceres::Problem the reference builds and solves inside those
  *                               functions (intrinsics.cpp:63-90, extrinsics.cpp:86-160,
  *                               bundle.cpp:83-133, detail/ceresutils.h:27-43,69-126); exposed so
@@ -257,6 +259,19 @@ cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_o
                                           const double* u, const double* v, const double* kmtx5, int32_t num_radial,
                                           double* pose7, const cba_options* opts, cba_summary* summaries, double* distortion,
                                           double* reprojection_error, double* cov36);
+
+/* optimize_homography (include/calib/estimation/optim/homography.h:17-18, src/estimation/optim/homography.cpp:144-175):
+ * refinement of the 8 free entries of a plane-to-image homography (H22 = 1), one 2-residual block PER
+ * CORRESPONDENCE, each with its own Huber loss (homography.cpp:132-142).  h9 in/out, row-major 3x3: the first 8
+ * entries are taken as given (HomographyBlocks::create :79-84), H22 comes back as 1.  Fewer than 4 correspondences:
+ * INVALID_ARGUMENT (:146-148).  cov64 = 8x8 covariance scaled by ssr / max(1, 2N - 8), ssr from the loss-corrected
+ * residuals (:163-173 evaluate the ceres::Problem with its default EvaluateOptions); zeros if rank deficient; may be
+ * NULL.  The _batch form refines n_views independent views in one launch (one wavefront per view). */
+cba_status cba_optimize_homography(int32_t n, const double* X, const double* Y, const double* u, const double* v,
+                                   double* h9, const cba_options* opts, cba_summary* summary, double* cov64);
+cba_status cba_optimize_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                         const double* u, const double* v, double* h9 /*[n_views][9]*/,
+                                         const cba_options* opts, cba_summary* summaries, double* cov64 /*[n_views][64]*/);
 
 #ifdef __cplusplus
 }

@@ -407,6 +407,53 @@ int orc_planar_pose_solve(int n, const double* X, const double* Y, const double*
     });
 }
 
+// ---- homography -------------------------------------------------------------------------------
+// residual (2) + Jacobian (2x8 row-major) of one correspondence
+void orc_homography_eval(const double* h8, double x, double y, double u, double v, double* r2, double* J28) {
+    HomographyBlock blk(x, y, u, v);
+    const double* xp[1] = {h8};
+    double* Jp[1] = {J28};
+    blk.evaluate(xp, r2, J28 ? Jp : nullptr);
+}
+
+// optimize_homography core (homography.cpp:144-175): h9 row-major in/out (first 8 entries are the parameters, H22 := 1);
+// cov64 = (J~^T J~)^-1 * ssr / max(1, 2N - 8) with ssr = sum of squared LOSS-CORRECTED residuals (:163-170 call
+// Problem::Evaluate with default EvaluateOptions, whose apply_loss_function is true — Ceres, third-party).
+int orc_homography_solve(int n, const double* X, const double* Y, const double* u, const double* v, double* h9,
+                         const cba_options* o, cba_summary* out, double* cov64) {
+    return guarded([&] {
+        if (n < 4) throw std::invalid_argument("At least 4 correspondences are required.");
+        Problem p;
+        const int id = p.add_param(h9, 8);
+        for (int i = 0; i < n; ++i) {
+            auto rb = std::make_unique<HomographyBlock>(X[i], Y[i], u[i], v[i]);
+            rb->pb = {id};
+            p.residuals.push_back(std::move(rb));
+        }
+        LMSummary s;
+        const auto t0 = std::chrono::steady_clock::now();
+        p.solve(to_lm(*o, 1), &s);
+        fill_summary(s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        h9[8] = 1.0;
+        if (cov64) {
+            double ssr = 0;
+            for (int i = 0; i < n; ++i) {
+                double r[2];
+                homography_residual<double>(h9, X[i], Y[i], u[i], v[i], r);
+                const double sq = r[0] * r[0] + r[1] * r[1];
+                double w = 1.0;
+                if (o->huber_delta > 0 && sq > o->huber_delta * o->huber_delta) w = o->huber_delta / std::sqrt(sq);
+                ssr += w * sq;
+            }
+            std::vector<double> c; int dim = 0;
+            if (p.covariance(to_lm(*o, 1), {id}, &c, &dim)) {
+                const double vf = ssr / std::max(1, 2 * n - 8);
+                for (int k = 0; k < 64; ++k) cov64[k] = c[k] * vf;
+            } else std::memset(cov64, 0, sizeof(double) * 64);
+        }
+    });
+}
+
 // ---- AX = XB ---------------------------------------------------------------------------------
 // residuals (6) + ambient Jacobians (6x4, 6x3) + tangent Jacobian (6x6) for one pair
 void orc_axxb_eval(const double* q, const double* t, const double* RA, const double* RB, const double* tA,

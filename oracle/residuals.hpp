@@ -221,6 +221,32 @@ struct PlanarPoseVPBlock final : ResidualBlock {
     }
 };
 
+// HomographyResidual::operator(), src/estimation/optim/homography.cpp:103-130: 8 parameters (H22 = 1),
+// uvw = H [x y 1]^T, residual = hnormalized(uvw) - (u, v); ONE residual block per correspondence (:132-142).
+template <typename T>
+inline void homography_residual(const T* h, double x, double y, double u, double v, T* r) {
+    const T uvw0 = h[0] * T(x) + h[1] * T(y) + h[2];
+    const T uvw1 = h[3] * T(x) + h[4] * T(y) + h[5];
+    const T uvw2 = h[6] * T(x) + h[7] * T(y) + T(1.0);
+    r[0] = uvw0 / uvw2 - T(u);
+    r[1] = uvw1 / uvw2 - T(v);
+}
+struct HomographyBlock final : ResidualBlock {
+    double x, y, u, v;
+    HomographyBlock(double x_, double y_, double u_, double v_) : x(x_), y(y_), u(u_), v(v_) { nres = 2; }
+    void evaluate(const double* const* p, double* r, double** J) const override {
+        if (!J) { homography_residual<double>(p[0], x, y, u, v, r); return; }
+        using JT = Jet<8>;
+        JT h[8], rj[2];
+        for (int k = 0; k < 8; ++k) h[k] = JT(p[0][k], k);
+        homography_residual<JT>(h, x, y, u, v, rj);
+        for (int i = 0; i < 2; ++i) {
+            r[i] = rj[i].a;
+            if (J[0]) for (int k = 0; k < 8; ++k) J[0][i * 8 + k] = rj[i].v[k];
+        }
+    }
+};
+
 inline std::unique_ptr<ResidualBlock> make_reproj_block(int chain, int model, const ViewData& v,
                                                         const double* bTg12) {
     auto fill = [&](auto* blk) {

@@ -37,6 +37,9 @@ def load_oracle():
                                      c_double_p, c_double_p]
     o.orc_planar_pose_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, PO, PS,
                                         c_double_p, c_double_p, c_double_p]
+    o.orc_homography_eval.argtypes = [c_double_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p]
+    o.orc_homography_eval.restype = None
+    o.orc_homography_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
     o.orc_quat_to_rotmat.argtypes = [c_double_p, c_double_p]
     o.orc_rotmat_to_quat.argtypes = [c_double_p, c_double_p]
     o.orc_quat_plus.argtypes = [c_double_p, c_double_p, c_double_p]
@@ -55,6 +58,9 @@ def load_hostmath():
                                     c_double_p, c_double_p, c_double_p, c_double_p]
     h.hm_planar_pose_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, PO, PS,
                                        c_double_p, c_double_p, c_double_p]
+    h.hm_homography_eval.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, c_double_p,
+                                     c_double_p, c_double_p]
+    h.hm_homography_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
     h.hm_quat_to_angle_axis.argtypes = [c_double_p, c_double_p]
     h.hm_angle_axis_to_quat.argtypes = [c_double_p, c_double_p]
     h.hm_handeye_last_error.restype = C.c_char_p
@@ -239,3 +245,58 @@ def pose6_of(T):
     else:
         aa = q[1:] * 2.0
     return np.ascontiguousarray(np.concatenate([aa, np.asarray(T)[:3, 3]]))
+
+
+# ---- homography (homography_test.cpp:21-48, 50-145) ------------------------------------------------
+def homography_true():
+    """generate_synthetic_data's ground truth (homography_test.cpp:24-28)."""
+    c, s = np.cos(0.1), np.sin(0.1)
+    return np.array([[c, -s, 10.0], [s, c, -5.0], [0.001, -0.002, 1.0]])
+
+
+def apply_homography(H, xy):
+    p = np.c_[xy, np.ones(len(xy))] @ np.asarray(H).T
+    return p[:, :2] / p[:, 2:3]
+
+
+def homography_scene(n_points=50, noise=0.0, n_outliers=0, seed=42):
+    """generate_synthetic_data (homography_test.cpp:21-48): points U(-100,100)^2, optional N(0, noise) on the image side;
+    n_outliers extra uniformly random pairs appended (:113-119).  numpy's generator, not libstdc++'s distributions:
+    the point sets differ from the reference binary's, the recipe and tolerances are the reference's."""
+    rng = np.random.default_rng(seed)
+    H = homography_true()
+    xy = rng.uniform(-100, 100, (n_points, 2))
+    uv = apply_homography(H, xy)
+    if noise > 0:
+        uv = uv + rng.normal(0, noise, uv.shape)
+    view = np.c_[xy, uv]
+    if n_outliers:
+        view = np.r_[view, rng.uniform(-100, 100, (n_outliers, 4))]
+    return np.ascontiguousarray(view), H
+
+
+def dlt_homography(view):
+    """Normalised DLT (Hartley) with H22 = 1 — test-side stand-in for estimate_homography, which is host code of
+    calib::estimation_linear (out of scope); only used to seed optimize_homography like the reference's tests do."""
+    view = np.asarray(view)
+
+    def norm(p):
+        c = p.mean(0)
+        s = np.sqrt(2.0) / np.mean(np.linalg.norm(p - c, axis=1))
+        return np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+
+    Ta, Tb = norm(view[:, :2]), norm(view[:, 2:])
+    a = apply_homography(Ta, view[:, :2])
+    b = apply_homography(Tb, view[:, 2:])
+    rows = []
+    for (x, y), (u, v) in zip(a, b):
+        rows.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
+        rows.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
+    h = np.linalg.svd(np.array(rows))[2][-1].reshape(3, 3)
+    H = np.linalg.inv(Tb) @ h @ Ta
+    return H / H[2, 2]
+
+
+def is_approx(a, b, tol):
+    """Eigen's isApprox: |a - b|_F <= tol * min(|a|_F, |b|_F)."""
+    return np.linalg.norm(a - b) <= tol * min(np.linalg.norm(a), np.linalg.norm(b))

@@ -410,3 +410,79 @@ def test_shared_and_distinct_target_point_lists(gpu_lib, oracle):
     assert (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
     assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
     assert abs(c - helpers.oracle_cost(oracle, flat)) <= 1e-10 * c
+
+
+def test_single_rank_transports_reproduce_the_plain_solve(gpu_lib):
+    """The two all-reduce transports of the multi-GPU path, with one rank (all a 1-GPU box allows): the RCCL
+    communicator inside libcalibba (ncclCommInitRank + ncclAllReduce on the engine's stream) and the host
+    callback must leave the solve bit-identical to the transport-free one (a sum over one rank is the identity)."""
+    o = options(epsilon=1e-10)
+
+    def run(setup):
+        sc = synth.scene_extrinsics(6, 3, noise_px=0.2, spacing=0.08)
+        with optim.ReprojHandle(sc.flat) as h:
+            setup(h)
+            s = h.solve(o)
+        return sc.flat, s
+
+    f0, s0 = run(lambda h: None)
+    f1, s1 = run(lambda h: h.init_rccl(optim.rccl_unique_id(), 1, 0))
+    calls = []
+
+    def cb(arr):
+        calls.append(arr.size)
+
+    f2, s2 = run(lambda h: h.set_allreduce(cb, 1, 0))
+    assert s0.success and s1.success and s2.success
+    for f, s in ((f1, s1), (f2, s2)):
+        assert s.iterations == s0.iterations and s.final_cost == s0.final_cost
+        assert np.array_equal(f.intr, f0.intr) and np.array_equal(f.cam_pose, f0.cam_pose)
+        assert np.array_equal(f.view_pose, f0.view_pose)
+
+
+# ---- optimize_homography: one wavefront per view, whole LM in-kernel ------------------------------------------
+def test_reference_kat_homography_on_gpu(gpu_lib):
+    """homography_test.cpp:50-145 through the mirror API."""
+    H = np.eye(3)
+    H[0, 2], H[1, 2] = 10.0, -5.0
+    xy = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], float)
+    view = np.c_[xy, helpers.apply_homography(H, xy)]
+    r = optim.optimize_homography(view, helpers.dlt_homography(view))
+    assert r.core.success and helpers.is_approx(r.homography, H, 1e-6)
+    view, H = helpers.homography_scene(50, 0.1)
+    r = optim.optimize_homography(view, helpers.dlt_homography(view))
+    assert r.core.success and helpers.is_approx(r.homography, H, 1e-2)
+    assert r.core.covariance is not None and r.core.covariance.shape == (8, 8)
+    view, H = helpers.homography_scene(100, 0.0, n_outliers=30)
+    r = optim.optimize_homography(view, helpers.dlt_homography(view[:100]))
+    assert r.core.success and helpers.is_approx(r.homography, H, 1e-2)
+    with pytest.raises(ValueError, match="At least 4"):
+        optim.optimize_homography(view[:3], np.eye(3))
+
+
+def test_homography_batch_matches_oracle(gpu_lib, oracle):
+    """A ragged batch (4 .. 3000 correspondences, with/without noise, outliers and loss) in one launch vs the oracle."""
+    rng = np.random.default_rng(11)
+    sizes = [4, 5, 63, 64, 65, 127, 128, 129, 500, 3000] + [int(k) for k in rng.integers(6, 400, 30)]
+    for delta in (1.0, -1.0):
+        views, inits = [], []
+        for i, n in enumerate(sizes):
+            noise = 0.0 if i % 3 == 0 else 0.3
+            nout = (n // 10) if (i % 4 == 1 and delta > 0) else 0
+            view, _ = helpers.homography_scene(n, noise, n_outliers=nout, seed=100 + i)
+            H0 = helpers.dlt_homography(view[:n]) * (1 + 1e-3)
+            H0[2, 2] = 1.0
+            views.append(view)
+            inits.append(H0)
+        res = optim.optimize_homography_batch(views, inits, optim.OptimOptions(huber_delta=delta))
+        o = options(huber_delta=delta)
+        for view, H0, r in zip(views, inits, res):
+            X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+            h, s, cov = H0.reshape(9).copy(), capi.CbaSummary(), np.zeros((8, 8))
+            assert oracle.orc_homography_solve(len(view), capi.dptr(X), capi.dptr(Y), capi.dptr(u), capi.dptr(v), capi.dptr(h), C.byref(o),
+                                               C.byref(s), capi.dptr(cov)) == 0
+            assert bool(s.success) == r.core.success and abs(s.iterations - r.core.iterations) <= 1 if hasattr(r.core, "iterations") else True
+            assert np.abs(h.reshape(3, 3) - r.homography).max() <= 1e-9 * max(1.0, np.abs(h).max()), len(view)
+            assert abs(s.final_cost - r.core.final_cost) <= 1e-9 * max(1.0, s.final_cost)
+            if np.any(cov) and r.core.covariance is not None and s.final_cost > 1e-12:
+                assert np.abs(cov - r.core.covariance).max() <= 1e-6 * np.abs(cov).max()

@@ -340,3 +340,48 @@ def test_vp_too_few_points_is_failure_not_exception(hostmath):
     assert hostmath.hm_planar_pose_solve(7, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(helpers.PLANAR_K), 0, dptr(p), C.byref(o), C.byref(s),
                                          dptr(d), C.byref(rms), dptr(None)) == 0
     assert s.termination == capi.TERM_FAILURE and not s.success
+
+
+# ---- homography: the product's per-view solver (hom_math.hpp + small_lm.hpp) on the single-thread group ------
+def test_homography_normal_equations_match_oracle_jets(oracle, hostmath):
+    """Per-correspondence Huber weights: H = sum w_i J_i^T J_i, g = sum w_i J_i^T r_i, cost = 1/2 sum rho(|r_i|^2)."""
+    view, H0 = helpers.homography_scene(40, 0.3, n_outliers=6, seed=5)
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    h = np.ascontiguousarray(H0.reshape(9)[:8] * (1 + 1e-3 * np.random.default_rng(1).uniform(-1, 1, 8)))
+    for delta in (1.0, -1.0):
+        Hn, g, cost = np.zeros((8, 8)), np.zeros(8), C.c_double()
+        assert hostmath.hm_homography_eval(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(h), delta, C.byref(cost), dptr(Hn), dptr(g)) == 0
+        He, ge, ce = np.zeros((8, 8)), np.zeros(8), 0.0
+        for x, y, uu, vv in view:
+            r, J = np.zeros(2), np.zeros((2, 8))
+            oracle.orc_homography_eval(dptr(h), x, y, uu, vv, dptr(r), dptr(J))
+            s = float(r @ r)
+            w, rho = (delta / np.sqrt(s), 2 * delta * np.sqrt(s) - delta * delta) if delta > 0 and s > delta * delta else (1.0, s)
+            He += w * J.T @ J
+            ge += w * J.T @ r
+            ce += 0.5 * rho
+        assert np.abs(Hn - He).max() <= 1e-12 * np.abs(He).max()
+        assert np.abs(g - ge).max() <= 1e-12 * max(1.0, np.abs(ge).max())
+        assert abs(cost.value - ce) <= 1e-12 * ce
+
+
+@pytest.mark.parametrize("n,noise,outliers,delta", [(50, 0.1, 0, 1.0), (100, 0.0, 30, 1.0), (60, 0.5, 5, -1.0), (4, 0.0, 0, 1.0)])
+def test_homography_lm_matches_oracle(oracle, hostmath, n, noise, outliers, delta):
+    view, H = helpers.homography_scene(n, noise, n_outliers=outliers)
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    H0 = helpers.dlt_homography(view[:n]) * (1 + 1e-3)
+    H0[2, 2] = 1.0
+    o = options(huber_delta=delta)
+    res = {}
+    for name, fn in (("oracle", oracle.orc_homography_solve), ("product", hostmath.hm_homography_solve)):
+        h, s, cov = H0.reshape(9).copy(), CbaSummary(), np.zeros((8, 8))
+        assert fn(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(h), C.byref(o), C.byref(s), dptr(cov)) == 0
+        res[name] = (h, s, cov)
+    (ha, sa, ca), (hb, sb, cb) = res["oracle"], res["product"]
+    assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and abs(sa.iterations - sb.iterations) <= 1
+    assert np.abs(ha - hb).max() <= 1e-9 * max(1.0, np.abs(ha).max())
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost)
+    if noise > 0:
+        assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
+    if outliers == 0 or delta > 0:
+        assert helpers.is_approx(hb.reshape(3, 3), H, 1e-2)

@@ -247,3 +247,62 @@ def test_oracle_input_validation(oracle):
     s = CbaSummary()
     o = options()
     assert oracle.orc_reproj_solve(C.byref(d), C.byref(o), 1, C.byref(s)) == capi.CBA_ERR_INVALID_ARGUMENT
+
+
+# ---- homography (tests/unit/homography_test.cpp) ----------------------------------------------------
+def _oracle_homography(oracle, view, H0, **okw):
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    h, s, cov = np.ascontiguousarray(H0, dtype=float).reshape(9).copy(), CbaSummary(), np.zeros((8, 8))
+    st = oracle.orc_homography_solve(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(h), C.byref(options(**okw)), C.byref(s), dptr(cov))
+    return st, h.reshape(3, 3), s, cov
+
+
+def test_homography_jacobian_matches_closed_form(oracle):
+    """The oracle's Jet Jacobian of HomographyResidual against the closed form and a complex-step derivative."""
+    rng = np.random.default_rng(3)
+    h = np.r_[helpers.homography_true().reshape(9)[:8]] * (1 + 0.01 * rng.uniform(-1, 1, 8))
+    for x, y, u, v in rng.uniform(-100, 100, (6, 4)):
+        r, J = np.zeros(2), np.zeros((2, 8))
+        oracle.orc_homography_eval(dptr(h), x, y, u, v, dptr(r), dptr(J))
+
+        def f(hc):
+            w = hc[6] * x + hc[7] * y + 1
+            return np.array([(hc[0] * x + hc[1] * y + hc[2]) / w - u, (hc[3] * x + hc[4] * y + hc[5]) / w - v])
+
+        assert np.abs(r - f(h).real).max() <= 1e-12
+        Jc = np.zeros((2, 8))
+        for k in range(8):
+            hc = h.astype(complex)
+            hc[k] += 1e-30j
+            Jc[:, k] = f(hc).imag / 1e-30
+        assert (np.abs(J - Jc) / np.maximum(1, np.abs(Jc))).max() <= 1e-12
+
+
+def test_reference_kat_homography_exact(oracle):
+    """HomographyTest.ExactHomography (homography_test.cpp:50-73): 4 exact points under a pure translation."""
+    H = np.eye(3)
+    H[0, 2], H[1, 2] = 10.0, -5.0
+    xy = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], float)
+    view = np.c_[xy, helpers.apply_homography(H, xy)]
+    st, Hr, s, _ = _oracle_homography(oracle, view, helpers.dlt_homography(view))
+    assert st == 0 and s.success
+    assert helpers.is_approx(Hr, H, 1e-6)
+
+
+def test_reference_kat_homography_noisy_and_outliers(oracle):
+    """NoisyHomography (:75-93, 50 pts, sigma 0.1, isApprox 1e-2) and RansacRecoversHomographyWithOutliers (:102-145,
+    100 exact + 30 random pairs, init from the inliers, refined over ALL pairs under the default Huber loss)."""
+    view, H = helpers.homography_scene(50, 0.1)
+    st, Hr, s, cov = _oracle_homography(oracle, view, helpers.dlt_homography(view))
+    assert st == 0 and s.success and helpers.is_approx(Hr, H, 1e-2)
+    assert np.linalg.eigvalsh(cov).min() > 0
+    view, H = helpers.homography_scene(100, 0.0, n_outliers=30)
+    st, Hr, s, _ = _oracle_homography(oracle, view, helpers.dlt_homography(view[:100]))
+    assert st == 0 and s.success and helpers.is_approx(Hr, H, 1e-2)
+
+
+def test_reference_kat_homography_insufficient_points(oracle):
+    """InsufficientPoints (:95-100): 3 correspondences -> std::invalid_argument."""
+    view = np.array([[0, 0, 10, 0], [1, 0, 11, 0], [0, 1, 10, 1]], float)
+    st, _, _, _ = _oracle_homography(oracle, view, np.eye(3))
+    assert st != 0 and b"At least 4" in oracle.orc_last_error()
