@@ -85,7 +85,7 @@ CBA_HD void hom_solve_view(const HomProblem& P, Coop& co, double eps, int max_it
     res.iterations = st.iterations; res.successful_steps = st.successful_steps; res.termination = st.termination;
     res.cov_ok = 0;
     for (int a = 0; a < 64; ++a) res.cov[a] = 0.0;
-    if (want_cov) {
+    if (want_cov && st.evaluated) {
         // homography.cpp:163-173: ssr from Problem::Evaluate (default EvaluateOptions apply the loss => robustified
         // residuals), n_res = 2N, scaled by ssr / max(1, 2N - 8) (ceresutils.h:117-123)
         const long long n_res = 2LL * P.n;

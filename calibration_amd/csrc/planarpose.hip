@@ -1,10 +1,11 @@
 // planarpose.hip — batched optimize_planar_pose (planarpose.cpp:84-127) on the GPU.
 //
-// k_planar_pose: ONE THREAD PER VIEW runs that view's entire variable-projection LM solve
-// (vp_math.hpp::vp_solve_view) in-kernel: no host round trips, views are independent problems (6 unknowns
-// each), and a batch of thousands of views fills the chip.  Every thread terminates after at most
-// max_iterations LM iterations, so the grid always drains.  The per-view inner loops stream that view's
-// X, Y, u, v (L2-resident after the first pass: 3 passes per evaluation).
+// k_planar_pose: ONE WAVEFRONT PER VIEW runs that view's entire variable-projection LM solve
+// (vp_math.hpp::vp_solve_view over small_lm.hpp's wave group) in-kernel: lanes stride over the view's points with
+// unit-stride loads, the three passes of an evaluation each end in one round of DPP wave sums, and every lane takes
+// the same 6x6 step.  No host round trips; views are independent problems (6 unknowns each) and a batch of thousands
+// of views fills the chip.  Every wave leaves after at most max_iterations LM iterations, so the grid always drains.
+// The view's X, Y, u, v stay L2-resident across the 3 passes per evaluation.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,20 +15,25 @@
 
 namespace cba {
 
-__global__ void k_planar_pose(int n_views, const int64_t* __restrict__ off, const double* __restrict__ X,
-                              const double* __restrict__ Y, const double* __restrict__ u, const double* __restrict__ v,
-                              const double* __restrict__ K5, int num_radial, double huber_delta, double eps, int max_iterations,
-                              int want_cov, VPResult* __restrict__ res) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_views) return;
+constexpr int VP_WAVES_PER_BLOCK = 4;
+
+template <int NR>
+__global__ __launch_bounds__(64 * VP_WAVES_PER_BLOCK) void k_planar_pose(
+    int n_views, const int64_t* __restrict__ off, const double* __restrict__ X, const double* __restrict__ Y,
+    const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ K5, int num_radial, double huber_delta,
+    double eps, int max_iterations, int want_cov, VPResult* __restrict__ res) {
+    const int i = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * VP_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+    if (i >= n_views) return;  // whole wave leaves together
     VPView V;
     V.n = static_cast<int>(off[i + 1] - off[i]);
     V.X = X + off[i]; V.Y = Y + off[i]; V.u = u + off[i]; V.v = v + off[i];
     for (int k = 0; k < 5; ++k) V.K[k] = K5[k];
     V.num_radial = num_radial;
-    VPResult r = res[i];
-    vp_solve_view(V, huber_delta, eps, max_iterations, want_cov != 0, r);
-    res[i] = r;
+    VPResult r;
+    for (int k = 0; k < 6; ++k) r.pose6[k] = res[i].pose6[k];
+    WaveCoop co;
+    vp_solve_view<NR>(V, co, huber_delta, eps, max_iterations, want_cov != 0, r);
+    if (co.lane() == 0) res[i] = r;
 }
 
 void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
@@ -59,9 +65,18 @@ void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X,
         }
         dres.upload(h.data(), n_views, stream);
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_planar_pose, dim3((n_views + 63) / 64), dim3(64), 0, stream, n_views, doff.p, dX.p, dY.p, du.p, dv.p,
-                           dK.p, num_radial, o->huber_delta, o->epsilon, o->max_iterations, (cov && o->compute_covariance) ? 1 : 0,
-                           dres.p);
+        const dim3 grid((n_views + VP_WAVES_PER_BLOCK - 1) / VP_WAVES_PER_BLOCK), block(64 * VP_WAVES_PER_BLOCK);
+        const int want_cov = (cov && o->compute_covariance) ? 1 : 0;
+#define CBA_VP_LAUNCH(NR)                                                                                                          \
+    hipLaunchKernelGGL(k_planar_pose<NR>, grid, block, 0, stream, n_views, doff.p, dX.p, dY.p, du.p, dv.p, dK.p, num_radial,       \
+                       o->huber_delta, o->epsilon, o->max_iterations, want_cov, dres.p)
+        switch (num_radial) {  // the design-matrix width nr + 2 is a compile-time constant of the kernel: no stack arrays
+            case 0: CBA_VP_LAUNCH(0); break;
+            case 1: CBA_VP_LAUNCH(1); break;
+            case 2: CBA_VP_LAUNCH(2); break;
+            default: CBA_VP_LAUNCH(3); break;
+        }
+#undef CBA_VP_LAUNCH
         CBA_HIP(hipGetLastError());
         dres.download(h.data(), n_views, stream);
         CBA_HIP(hipStreamSynchronize(stream));

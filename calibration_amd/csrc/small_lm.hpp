@@ -81,6 +81,7 @@ struct SmallLMState {
     double g[NP];       // J~^T r~
     double cost, initial_cost;
     int iterations, successful_steps, termination;
+    int evaluated;  // 0 when the functor failed at x0 (H, g undefined)
 };
 
 // Problem concept:
@@ -94,7 +95,9 @@ CBA_HD void small_lm_solve(const Problem& P, Coop& co, double eps, int max_itera
     double cand[NP], delta[NP], scale2[NP], A[NP * NP];
     st.iterations = 0; st.successful_steps = 0; st.termination = CBA_TERM_FAILURE;
     st.cost = st.initial_cost = 0.0;
+    st.evaluated = 0;
     if (!P.evaluate(co, st.x, true, &st.cost, st.H, st.g, &aux)) return;  // evaluation failure at x0: Ceres reports FAILURE
+    st.evaluated = 1;
     st.initial_cost = st.cost;
     for (int i = 0; i < NP; ++i) { const double sc = 1.0 / (1.0 + sqrt(st.H[i * NP + i])); scale2[i] = sc * sc; }
     double gmax = 0.0;

@@ -1,6 +1,6 @@
 // vp_math.hpp — planar-pose refinement by variable projection, one whole Levenberg-Marquardt solve per
-// view as __host__ __device__ inline code (kernel: planarpose.hip, one GPU thread per view, batched over
-// views; CPU test build: tests/cpu_backend).
+// view as __host__ __device__ inline code (kernel: planarpose.hip, ONE WAVEFRONT per view through the cooperative
+// solver of small_lm.hpp, batched over views; CPU test build: tests/cpu_backend with the single-thread group).
 //
 // Reference: optimize_planar_pose src/estimation/optim/planarpose.cpp:84-127 with the functor
 // PlanarPoseVPResidual (:39-57): pose6 = [angle-axis(3), t(3)] (no manifold), each evaluation builds the
@@ -12,11 +12,12 @@
 //     dr/dp_k = P_perp (dA_k alpha - db_k) - A (A^T A)^-1 dA_k^T r,     P_perp = I - A (A^T A)^-1 A^T
 // With per-row scalars q = (dA_row/d(x,y)) alpha - db_row/d(x,y) this needs three passes over the points:
 //   1. A^T A, A^T b -> alpha          2. r, |r|^2, G_k = A^T w_k + dA_k^T r          3. J rows -> J^T J, J^T r
-// LM semantics: the same restated Ceres trust-region rules as lm_core.hpp (unconstrained Euclidean block).
+// LM semantics: small_lm.hpp (the same restated Ceres trust-region rules as lm_core.hpp, unconstrained Euclidean block).
 #pragma once
 #include "../../include/calibba.h"
 #include "reproj_math.hpp"
 #include "schur_math.hpp"
+#include "small_lm.hpp"
 
 namespace cba {
 
@@ -81,9 +82,10 @@ struct VPRow {
     double dx[6], dy[6];
 };
 
+template <int NR>
 CBA_HD void vp_row(const VPView& V, const double* pose6, int i, bool deriv, VPRow& R) {
     const double fx = V.K[0], fy = V.K[1], cx = V.K[2], cy = V.K[3], skew = V.K[4];
-    const int nr = V.num_radial;
+    constexpr int nr = NR;
     const double pt[3] = {V.X[i], V.Y[i], 0.0};
     double pc[3], dRda[9];
     aa_rotate(pose6, pt, pc, deriv ? dRda : nullptr);
@@ -128,7 +130,8 @@ CBA_HD void vp_row(const VPView& V, const double* pose6, int i, bool deriv, VPRo
 }
 
 // small SPD solve (m <= 5), in place lower Cholesky of M (row-major m x m); false if not PD
-CBA_HD bool vp_chol(double* M, int m) {
+template <int m>
+CBA_HD bool vp_chol(double* M) {
     for (int j = 0; j < m; ++j) {
         double d = M[j * m + j];
         for (int k = 0; k < j; ++k) d -= M[j * m + k] * M[j * m + k];
@@ -143,7 +146,8 @@ CBA_HD bool vp_chol(double* M, int m) {
     }
     return true;
 }
-CBA_HD void vp_chol_solve(const double* L, int m, double* b) {
+template <int m>
+CBA_HD void vp_chol_solve(const double* L, double* b) {
     for (int i = 0; i < m; ++i) {
         double s = b[i];
         for (int k = 0; k < i; ++k) s -= L[i * m + k] * b[k];
@@ -158,29 +162,37 @@ CBA_HD void vp_chol_solve(const double* L, int m, double* b) {
 
 // Evaluate at pose6: alpha, s = |r|^2 and (if want_jac) the UNWEIGHTED H = J^T J (36, full), g = J^T r (6).
 // Returns false when fit_distortion_full would fail (N < 8, distortion.h:236-239) or A^T A is singular.
-CBA_HD bool vp_evaluate(const VPView& V, const double* pose6, bool want_jac, double* alpha, double* s_out, double* H,
+// `co` is the cooperative group that owns the view (small_lm.hpp): its lanes stride over the points and the
+// partial sums of each pass cross the group once; every lane leaves with identical results.
+template <int NR, class Coop>
+CBA_HD bool vp_evaluate(const VPView& V, Coop& co, const double* pose6, bool want_jac, double* alpha, double* s_out, double* H,
                         double* g) {
-    const int m = V.num_radial + 2, N = V.n;
+    constexpr int m = NR + 2;
+    const int N = V.n;
     if (N < 8) return false;
     double M[VP_MAX_M * VP_MAX_M], rhs[VP_MAX_M];
-    for (int a = 0; a < m * m; ++a) M[a] = 0.0;
-    for (int a = 0; a < m; ++a) rhs[a] = 0.0;
+    for (int a = 0; a < VP_MAX_M * VP_MAX_M; ++a) M[a] = 0.0;
+    for (int a = 0; a < VP_MAX_M; ++a) rhs[a] = 0.0;
     VPRow R;
-    for (int i = 0; i < N; ++i) {  // pass 1
-        vp_row(V, pose6, i, false, R);
+    for (int i = co.lane(); i < N; i += co.width()) {  // pass 1
+        vp_row<NR>(V, pose6, i, false, R);
         for (int a = 0; a < m; ++a) {
             rhs[a] += R.Au[a] * R.bu + R.Av[a] * R.bv;
             for (int c = 0; c <= a; ++c) M[a * m + c] += R.Au[a] * R.Au[c] + R.Av[a] * R.Av[c];
         }
     }
-    if (!vp_chol(M, m)) return false;
+    for (int a = 0; a < m; ++a) {
+        rhs[a] = co.sum(rhs[a]);
+        for (int c = 0; c <= a; ++c) M[a * m + c] = co.sum(M[a * m + c]);
+    }
+    if (!vp_chol<m>(M)) return false;
     for (int a = 0; a < m; ++a) alpha[a] = rhs[a];
-    vp_chol_solve(M, m, alpha);
+    vp_chol_solve<m>(M, alpha);
     double s = 0.0;
     double G[6][VP_MAX_M];
-    for (int k = 0; k < 6; ++k) for (int a = 0; a < m; ++a) G[k][a] = 0.0;
-    for (int i = 0; i < N; ++i) {  // pass 2
-        vp_row(V, pose6, i, want_jac, R);
+    for (int k = 0; k < 6; ++k) for (int a = 0; a < VP_MAX_M; ++a) G[k][a] = 0.0;
+    for (int i = co.lane(); i < N; i += co.width()) {  // pass 2
+        vp_row<NR>(V, pose6, i, want_jac, R);
         double ru = -R.bu, rv = -R.bv;
         for (int a = 0; a < m; ++a) { ru += R.Au[a] * alpha[a]; rv += R.Av[a] * alpha[a]; }
         s += ru * ru + rv * rv;
@@ -197,13 +209,17 @@ CBA_HD bool vp_evaluate(const VPView& V, const double* pose6, bool want_jac, dou
                            (R.Avx[a] * R.dx[k] + R.Avy[a] * R.dy[k]) * rv;
         }
     }
-    *s_out = s;
+    *s_out = co.sum(s);
     if (!want_jac) return true;
-    for (int k = 0; k < 6; ++k) vp_chol_solve(M, m, G[k]);  // c_k = (A^T A)^-1 G_k
-    for (int a = 0; a < 36; ++a) H[a] = 0.0;
-    for (int a = 0; a < 6; ++a) g[a] = 0.0;
-    for (int i = 0; i < N; ++i) {  // pass 3
-        vp_row(V, pose6, i, true, R);
+    for (int k = 0; k < 6; ++k) {
+        for (int a = 0; a < m; ++a) G[k][a] = co.sum(G[k][a]);
+        vp_chol_solve<m>(M, G[k]);  // c_k = (A^T A)^-1 G_k
+    }
+    double Hs[21], gs[6];  // upper triangle of H, row-major
+    for (int a = 0; a < 21; ++a) Hs[a] = 0.0;
+    for (int a = 0; a < 6; ++a) gs[a] = 0.0;
+    for (int i = co.lane(); i < N; i += co.width()) {  // pass 3
+        vp_row<NR>(V, pose6, i, true, R);
         double ru = -R.bu, rv = -R.bv;
         double qux = -R.bux, quy = -R.buy, qvx = -R.bvx, qvy = -R.bvy;
         for (int a = 0; a < m; ++a) {
@@ -217,117 +233,71 @@ CBA_HD bool vp_evaluate(const VPView& V, const double* pose6, bool want_jac, dou
             for (int a = 0; a < m; ++a) { ju -= R.Au[a] * G[k][a]; jv -= R.Av[a] * G[k][a]; }
             Ju[k] = ju; Jv[k] = jv;
         }
+        int k = 0;
         for (int a = 0; a < 6; ++a) {
-            g[a] += Ju[a] * ru + Jv[a] * rv;
-            for (int c = 0; c < 6; ++c) H[a * 6 + c] += Ju[a] * Ju[c] + Jv[a] * Jv[c];
+            gs[a] += Ju[a] * ru + Jv[a] * rv;
+            for (int c = a; c < 6; ++c, ++k) Hs[k] += Ju[a] * Ju[c] + Jv[a] * Jv[c];
+        }
+    }
+    int k = 0;
+    for (int a = 0; a < 6; ++a) {
+        g[a] = co.sum(gs[a]);
+        for (int c = a; c < 6; ++c, ++k) {
+            const double t = co.sum(Hs[k]);
+            H[a * 6 + c] = t;
+            H[c * 6 + a] = t;
         }
     }
     return true;
 }
 
-// The whole solve for one view.  pose6 in `res.pose6` on entry (initial guess) and exit (result).
-CBA_HD void vp_solve_view(const VPView& V, double huber_delta, double eps, int max_iterations, bool want_cov, VPResult& res) {
-    double x[6], cand[6], alpha[VP_MAX_M], H[36], g[6], A[36], delta[6], scale2[6], s = 0.0;
-    for (int k = 0; k < 6; ++k) x[k] = res.pose6[k];
-    for (int a = 0; a < VP_MAX_M; ++a) { alpha[a] = 0.0; res.alpha[a] = 0.0; }
-    res.iterations = 0; res.successful_steps = 0; res.termination = CBA_TERM_FAILURE; res.cov_ok = 0;
-    res.initial_cost = res.final_cost = res.rms = 0.0;
-    for (int a = 0; a < 36; ++a) res.cov[a] = 0.0;
-    if (!vp_evaluate(V, x, true, alpha, &s, H, g)) return;  // evaluation failure at x0: Ceres reports FAILURE
-    double rho, w;
-    huber(s, huber_delta, &rho, &w);
-    double cost = 0.5 * rho;
-    res.initial_cost = cost;
-    for (int a = 0; a < 36; ++a) H[a] *= w;
-    for (int a = 0; a < 6; ++a) g[a] *= w;
-    for (int i = 0; i < 6; ++i) { const double sc = 1.0 / (1.0 + sqrt(H[i * 6 + i])); scale2[i] = sc * sc; }
-    double gmax = 0.0;
-    for (int i = 0; i < 6; ++i) gmax = fmax(gmax, fabs(g[i]));
-    double radius = 1e4, decrease_factor = 2.0;
-    int iter = 0, invalid = 0, term = CBA_TERM_FAILURE;
-    if (gmax <= eps) term = CBA_TERM_CONVERGENCE;
-    else while (true) {
-        if (iter >= max_iterations) { term = CBA_TERM_NO_CONVERGENCE; break; }
-        if (gmax <= eps) { term = CBA_TERM_CONVERGENCE; break; }
-        if (radius <= 1e-32) { term = CBA_TERM_CONVERGENCE; break; }
-        ++iter;
-        for (int a = 0; a < 36; ++a) A[a] = H[a];
-        for (int i = 0; i < 6; ++i) A[i * 6 + i] += lm_diag(H[i * 6 + i], scale2[i], radius);
-        bool valid = chol6(A);
-        double model_change = 0.0;
-        if (valid) {
-            for (int i = 0; i < 6; ++i) delta[i] = -g[i];
-            fwd6(A, delta);
-            bwd6(A, delta);
-            double dg = 0.0, dHd = 0.0;
-            for (int i = 0; i < 6; ++i) {
-                dg += delta[i] * g[i];
-                double t = 0.0;
-                for (int j = 0; j < 6; ++j) t += H[i * 6 + j] * delta[j];
-                dHd += delta[i] * t;
-                if (!(delta[i] == delta[i]) || fabs(delta[i]) > 1e300) valid = false;
-            }
-            model_change = -dg - 0.5 * dHd;
-            if (!(model_change > 0.0)) valid = false;
+// optimize_planar_pose as a small_lm problem: ONE residual block (all 2N residuals) under one Huber loss
+// (planarpose.cpp:99-102), so the loss weight is a scalar of the whole evaluation.
+struct VPAux {
+    double alpha[VP_MAX_M];
+    double s;  // |r|^2, unweighted
+};
+template <int NR>
+struct VPProblem {
+    using Aux = VPAux;
+    VPView V;
+    double huber_delta;
+    template <class Coop>
+    CBA_HD bool evaluate(Coop& co, const double* pose6, bool want_jac, double* cost, double* H, double* g, Aux* aux) const {
+        for (int a = 0; a < VP_MAX_M; ++a) aux->alpha[a] = 0.0;
+        if (!vp_evaluate<NR>(V, co, pose6, want_jac, aux->alpha, &aux->s, H, g)) return false;
+        double rho, w;
+        huber(aux->s, huber_delta, &rho, &w);
+        *cost = 0.5 * rho;
+        if (want_jac) {
+            for (int a = 0; a < 36; ++a) H[a] *= w;
+            for (int a = 0; a < 6; ++a) g[a] *= w;
         }
-        if (!valid) {
-            if (++invalid >= 5) { term = CBA_TERM_FAILURE; break; }
-            radius *= 0.5;
-            continue;
-        }
-        invalid = 0;
-        for (int k = 0; k < 6; ++k) cand[k] = x[k] + delta[k];
-        double calpha[VP_MAX_M], cs = 0.0, cH[36], cg[6];
-        // one evaluation gives the candidate cost and, if the step is accepted, its Jacobian
-        double cand_cost = 1.7976931348623157e308;
-        const bool ok = vp_evaluate(V, cand, true, calpha, &cs, cH, cg);
-        double crho = 0.0, cw = 1.0;
-        if (ok) { huber(cs, huber_delta, &crho, &cw); cand_cost = 0.5 * crho; }
-        double sn = 0.0, xn = 0.0;
-        for (int k = 0; k < 6; ++k) { sn += delta[k] * delta[k]; xn += x[k] * x[k]; }
-        if (sqrt(sn) <= eps * (sqrt(xn) + eps)) { term = CBA_TERM_CONVERGENCE; break; }
-        const double cost_change = cost - cand_cost;
-        if (fabs(cost_change) <= eps * cost) { term = CBA_TERM_CONVERGENCE; break; }
-        const double rel = cost_change / model_change;
-        if (rel > 1e-3) {
-            for (int k = 0; k < 6; ++k) x[k] = cand[k];
-            for (int a = 0; a < VP_MAX_M; ++a) alpha[a] = calpha[a];
-            s = cs; cost = cand_cost; w = cw;
-            for (int a = 0; a < 36; ++a) H[a] = cw * cH[a];
-            for (int a = 0; a < 6; ++a) g[a] = cw * cg[a];
-            ++res.successful_steps;
-            gmax = 0.0;
-            for (int i = 0; i < 6; ++i) gmax = fmax(gmax, fabs(g[i]));
-            const double t = 2.0 * rel - 1.0;
-            radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-            if (radius > 1e16) radius = 1e16;
-            decrease_factor = 2.0;
-        } else {
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-        }
+        return true;
     }
-    for (int k = 0; k < 6; ++k) res.pose6[k] = x[k];
-    const int m = V.num_radial + 2;
-    for (int a = 0; a < m; ++a) res.alpha[a] = alpha[a];
-    res.iterations = iter;
-    res.termination = term;
-    res.final_cost = cost;
-    res.rms = sqrt(s / (2.0 * V.n));  // planarpose.cpp:112-114
-    if (want_cov) {  // ceresutils.h:69-126 with (ssr, n_res): (J~^T J~)^-1 * ssr / max(1, 2N - 6)
-        for (int a = 0; a < 36; ++a) A[a] = H[a];
-        if (chol6(A)) {
-            const int dof = 2 * V.n - 6 > 1 ? 2 * V.n - 6 : 1;
-            const double vf = s / dof;
-            for (int c = 0; c < 6; ++c) {
-                double e[6] = {0, 0, 0, 0, 0, 0};
-                e[c] = 1.0;
-                fwd6(A, e);
-                bwd6(A, e);
-                for (int r = 0; r < 6; ++r) res.cov[r * 6 + c] = e[r] * vf;
-            }
-            res.cov_ok = 1;
-        }
+};
+
+// The whole solve for one view.  pose6 in `res.pose6` on entry (initial guess) and exit (result).
+template <int NR, class Coop>
+CBA_HD void vp_solve_view(const VPView& V, Coop& co, double huber_delta, double eps, int max_iterations, bool want_cov, VPResult& res) {
+    VPProblem<NR> P{V, huber_delta};
+    SmallLMState<6> st;
+    for (int k = 0; k < 6; ++k) st.x[k] = res.pose6[k];
+    VPAux aux;
+    for (int a = 0; a < VP_MAX_M; ++a) aux.alpha[a] = 0.0;
+    aux.s = 0.0;
+    small_lm_solve<6>(P, co, eps, max_iterations, st, aux);
+    for (int k = 0; k < 6; ++k) res.pose6[k] = st.x[k];
+    for (int a = 0; a < VP_MAX_M; ++a) res.alpha[a] = aux.alpha[a];
+    res.iterations = st.iterations; res.successful_steps = st.successful_steps; res.termination = st.termination;
+    res.initial_cost = st.initial_cost; res.final_cost = st.cost;
+    res.rms = st.evaluated ? sqrt(aux.s / (2.0 * V.n)) : 0.0;  // planarpose.cpp:112-114
+    res.cov_ok = 0;
+    for (int a = 0; a < 36; ++a) res.cov[a] = 0.0;
+    if (want_cov && st.evaluated) {  // ceresutils.h:69-126 with (ssr, n_res): (J~^T J~)^-1 * ssr / max(1, 2N - 6)
+        const long long n_res = 2LL * V.n;
+        const long long dof = n_res - 6 > 1 ? n_res - 6 : 1;
+        res.cov_ok = small_covariance<6>(st.H, n_res, aux.s / static_cast<double>(dof), res.cov) ? 1 : 0;
     }
 }
 

@@ -481,7 +481,7 @@ def test_homography_batch_matches_oracle(gpu_lib, oracle):
             h, s, cov = H0.reshape(9).copy(), capi.CbaSummary(), np.zeros((8, 8))
             assert oracle.orc_homography_solve(len(view), capi.dptr(X), capi.dptr(Y), capi.dptr(u), capi.dptr(v), capi.dptr(h), C.byref(o),
                                                C.byref(s), capi.dptr(cov)) == 0
-            assert bool(s.success) == r.core.success and abs(s.iterations - r.core.iterations) <= 1 if hasattr(r.core, "iterations") else True
+            assert bool(s.success) == r.core.success and abs(s.iterations - r.core.iterations) <= 1
             assert np.abs(h.reshape(3, 3) - r.homography).max() <= 1e-9 * max(1.0, np.abs(h).max()), len(view)
             assert abs(s.final_cost - r.core.final_cost) <= 1e-9 * max(1.0, s.final_cost)
             if np.any(cov) and r.core.covariance is not None and s.final_cost > 1e-12:
