@@ -50,25 +50,43 @@ __global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, c
     }
 }
 
-// out[o][e] = sum_{t in [seg[o], seg[o+1])} rows[t][e]   (fixed order)
-__global__ void k_seg_sum(int n_out, int width, const int64_t* __restrict__ seg, const double* __restrict__ rows,
-                          double* __restrict__ out) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= static_cast<int64_t>(n_out) * width) return;
-    const int o = static_cast<int>(idx / width);
-    const int e = static_cast<int>(idx % width);
+// Column sums of a row-major partial table in a FIXED order, 8 row groups per column: thread (column c, group r)
+// adds rows r, r+8, r+16, ... and the 8 group sums are combined in group order through LDS — 8x the parallelism
+// and 1/8 the dependent chain of one thread per column (125 chunk rows at 1000 views, 500 at 4000).
+constexpr int RS_COLS = 32, RS_GROUPS = 8;
+
+__device__ __forceinline__ double grouped_column_sum(const double* __restrict__ rows, int64_t t0, int64_t t1, int64_t width,
+                                                     int64_t e, bool valid, double (*sh)[RS_COLS]) {
+    const int c = threadIdx.x % RS_COLS, r = threadIdx.x / RS_COLS;
     double s = 0.0;
-    for (int64_t t = seg[o]; t < seg[o + 1]; ++t) s += rows[t * width + e];
-    out[idx] = s;
+    if (valid)
+        for (int64_t t = t0 + r; t < t1; t += RS_GROUPS) s += rows[t * width + e];
+    sh[r][c] = s;
+    __syncthreads();
+    double tot = 0.0;
+    if (r == 0)
+        for (int k = 0; k < RS_GROUPS; ++k) tot += sh[k][c];
+    __syncthreads();
+    return tot;
 }
 
-// out[e] = sum_{t < n_rows} rows[t][e]
-__global__ void k_row_sum(int64_t n_rows, int64_t width, const double* __restrict__ rows, double* __restrict__ out) {
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= width) return;
-    double s = 0.0;
-    for (int64_t t = 0; t < n_rows; ++t) s += rows[t * width + e];
-    out[e] = s;
+// out[o][e] = sum_{t in [seg[o], seg[o+1])} rows[t][e]; grid (ceil(width / 32), n_out), 256 threads
+__global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_seg_sum(int n_out, int width, const int64_t* __restrict__ seg,
+                                                                  const double* __restrict__ rows, double* __restrict__ out) {
+    __shared__ double sh[RS_GROUPS][RS_COLS];
+    const int o = blockIdx.y;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * RS_COLS + threadIdx.x % RS_COLS;
+    const double tot = grouped_column_sum(rows, seg[o], seg[o + 1], width, e, e < width, sh);
+    if (threadIdx.x < RS_COLS && e < width) out[static_cast<int64_t>(o) * width + e] = tot;
+}
+
+// out[e] = sum_{t < n_rows} rows[t][e]; grid ceil(width / 32), 256 threads
+__global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_row_sum(int64_t n_rows, int64_t width, const double* __restrict__ rows,
+                                                                  double* __restrict__ out) {
+    __shared__ double sh[RS_GROUPS][RS_COLS];
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * RS_COLS + threadIdx.x % RS_COLS;
+    const double tot = grouped_column_sum(rows, 0, n_rows, width, e, e < width, sh);
+    if (threadIdx.x < RS_COLS && e < width) out[e] = tot;
 }
 
 // single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4), out[w] = max_i aux[i] (if aux)
@@ -238,7 +256,7 @@ struct HipBackend final : Backend {
                            e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
         hipLaunchKernelGGL(k_cam_partial, dim3(std::max(1, st.n_cchunks)), dim3(256), 0, e.stream, s.NACC, st.cchunk_off.p,
                            st.cam_blk.p, e.blk_w.p, e.blk_acc.p, st.cam_partial.p);
-        hipLaunchKernelGGL(k_seg_sum, dim3(nblk(static_cast<int64_t>(s.n_cams) * s.NACC, 256)), dim3(256), 0, e.stream, s.n_cams,
+        hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
                            s.NACC, st.cam_seg.p, st.cam_partial.p, e.cam_acc.p);
         launch_cost(e, huber);
         CBA_HIP(hipGetLastError());
@@ -264,11 +282,11 @@ struct HipBackend final : Backend {
         hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
                            st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
-        hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, 256)), dim3(256), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
+        hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
                            st.syrk_partial.p, st.schur_pack.p);
         hipLaunchKernelGGL(k_schur_gvec, dim3(st.n_vchunks), dim3(128), 0, e.stream, st.dims, s.n_views, n, st.view_cam_blk.p,
                            e.blk_Z.p, e.view_y.p, st.gvec_partial.p);
-        hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, 128)), dim3(128), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
+        hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
                            static_cast<int64_t>(n), st.gvec_partial.p, st.schur_pack.p + sw);
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
                            st.schur_pack.p + sw + n);
