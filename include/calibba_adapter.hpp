@@ -10,6 +10,8 @@
 //   calib::optimize_extrinsics<CameraT>                    src/estimation/optim/extrinsics.cpp:174-196
 //   calib::optimize_bundle<CameraT>                        src/estimation/optim/bundle.cpp:147-170
 //   calib::optimize_handeye                                src/estimation/optim/handeye.cpp:60-78
+//   calib::optimize_planar_pose                            src/estimation/optim/planarpose.cpp:84-127
+//   calib::optimize_homography                             src/estimation/optim/homography.cpp:144-175
 #pragma once
 #include <Eigen/Geometry>
 #include <array>
@@ -19,7 +21,9 @@
 #include "calib/estimation/optim/bundle.h"
 #include "calib/estimation/optim/extrinsics.h"
 #include "calib/estimation/optim/handeye.h"
+#include "calib/estimation/optim/homography.h"
 #include "calib/estimation/optim/intrinsics.h"
+#include "calib/estimation/optim/planarpose.h"
 #include "calib/models/scheimpflug.h"
 #include "calibba.h"
 
@@ -214,6 +218,55 @@ inline auto optimize_handeye(const std::vector<Eigen::Isometry3d>& base_se3_grip
     calib::HandeyeResult res;
     res.g_se3_c = pose_out(x.data());
     fill_core(sum, o, cov, 7, res.core);
+    return res;
+}
+
+inline void flatten_view(const calib::PlanarView& view, std::vector<double>& X, std::vector<double>& Y, std::vector<double>& u,
+                         std::vector<double>& v) {
+    X.reserve(view.size()); Y.reserve(view.size()); u.reserve(view.size()); v.reserve(view.size());
+    for (const auto& ob : view) {
+        X.push_back(ob.object_xy.x()); Y.push_back(ob.object_xy.y());
+        u.push_back(ob.image_uv.x()); v.push_back(ob.image_uv.y());
+    }
+}
+
+inline auto optimize_planar_pose(const calib::PlanarView& view, const calib::CameraMatrix& intrinsics,
+                                 const Eigen::Isometry3d& init_pose, const calib::PlanarPoseOptions& opts = {})
+    -> calib::PlanarPoseResult {
+    std::vector<double> X, Y, u, v;
+    flatten_view(view, X, Y, u, v);
+    const double K[5] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy, intrinsics.skew};
+    double p7[7], rms = 0.0;
+    pose_in(init_pose, p7);
+    std::vector<double> dist(static_cast<size_t>(opts.num_radial) + 2), cov(36);
+    cba_options o = make_options(opts.core);
+    cba_summary sum{};
+    check(cba_optimize_planar_pose(static_cast<int32_t>(view.size()), X.data(), Y.data(), u.data(), v.data(), K, opts.num_radial, p7,
+                                   &o, &sum, dist.data(), &rms, cov.data()));
+    calib::PlanarPoseResult res;
+    res.pose = pose_out(p7);
+    res.distortion = Eigen::Map<const Eigen::VectorXd>(dist.data(), static_cast<Eigen::Index>(dist.size()));
+    res.reprojection_error = rms;
+    fill_core(sum, o, cov, 6, res.core);
+    return res;
+}
+
+inline auto optimize_homography(const calib::PlanarView& data, const Eigen::Matrix3d& init_h, const calib::OptimOptions& options = {})
+    -> calib::OptimizeHomographyResult {
+    if (data.size() < 4) throw std::invalid_argument("At least 4 correspondences are required.");  // homography.cpp:146-148
+    std::vector<double> X, Y, u, v;
+    flatten_view(data, X, Y, u, v);
+    double h9[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) h9[3 * r + c] = init_h(r, c);  // row-major, as HomographyBlocks::create reads it
+    std::vector<double> cov(64);
+    cba_options o = make_options(options);
+    cba_summary sum{};
+    check(cba_optimize_homography(static_cast<int32_t>(data.size()), X.data(), Y.data(), u.data(), v.data(), h9, &o, &sum, cov.data()));
+    calib::OptimizeHomographyResult res;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) res.homography(r, c) = h9[3 * r + c];
+    fill_core(sum, o, cov, 8, res.core);
     return res;
 }
 
