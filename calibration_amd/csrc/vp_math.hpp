@@ -82,16 +82,12 @@ struct VPRow {
     double dx[6], dy[6];
 };
 
+// The two design rows of one observation at normalised coordinates (x, y): Au, Av (m = NR + 2), b, and (deriv) their
+// x- and y-derivatives (distortion.h:254-288).  K = [fx fy cx cy skew].
 template <int NR>
-CBA_HD void vp_row(const VPView& V, const double* pose6, int i, bool deriv, VPRow& R) {
-    const double fx = V.K[0], fy = V.K[1], cx = V.K[2], cy = V.K[3], skew = V.K[4];
+CBA_HD void vp_design(const double* K, double x, double y, double uo, double vo, bool deriv, VPRow& R) {
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], skew = K[4];
     constexpr int nr = NR;
-    const double pt[3] = {V.X[i], V.Y[i], 0.0};
-    double pc[3], dRda[9];
-    aa_rotate(pose6, pt, pc, deriv ? dRda : nullptr);
-    for (int k = 0; k < 3; ++k) pc[k] += pose6[3 + k];
-    const double iz = 1.0 / pc[2];
-    const double x = pc[0] * iz, y = pc[1] * iz;
     const double r2 = x * x + y * y;
     const double g = fx * x + skew * y, h = fy * y;
     double rpow = r2, rprev = 1.0;  // rho^(j+1), rho^j
@@ -112,14 +108,26 @@ CBA_HD void vp_row(const VPView& V, const double* pose6, int i, bool deriv, VPRo
     R.Au[nr + 1] = fx * (r2 + 2.0 * x * x) + skew * (2.0 * x * y);
     R.Av[nr] = fy * (r2 + 2.0 * y * y);
     R.Av[nr + 1] = fy * (2.0 * x * y);
-    R.bu = V.u[i] - (g + cx);
-    R.bv = V.v[i] - (h + cy);
+    R.bu = uo - (g + cx);
+    R.bv = vo - (h + cy);
     if (!deriv) return;
     R.Aux[nr] = fx * 2.0 * y + skew * 2.0 * x;       R.Auy[nr] = fx * 2.0 * x + skew * 6.0 * y;
     R.Aux[nr + 1] = fx * 6.0 * x + skew * 2.0 * y;   R.Auy[nr + 1] = fx * 2.0 * y + skew * 2.0 * x;
     R.Avx[nr] = fy * 2.0 * x;                        R.Avy[nr] = fy * 6.0 * y;
     R.Avx[nr + 1] = fy * 2.0 * y;                    R.Avy[nr + 1] = fy * 2.0 * x;
     R.bux = -fx; R.buy = -skew; R.bvx = 0.0; R.bvy = -fy;
+}
+
+template <int NR>
+CBA_HD void vp_row(const VPView& V, const double* pose6, int i, bool deriv, VPRow& R) {
+    const double pt[3] = {V.X[i], V.Y[i], 0.0};
+    double pc[3], dRda[9];
+    aa_rotate(pose6, pt, pc, deriv ? dRda : nullptr);
+    for (int k = 0; k < 3; ++k) pc[k] += pose6[3 + k];
+    const double iz = 1.0 / pc[2];
+    const double x = pc[0] * iz, y = pc[1] * iz;
+    vp_design<NR>(V.K, x, y, V.u[i], V.v[i], deriv, R);
+    if (!deriv) return;
     // d(x, y)/d pose6: d pc/d aa = dRda, d pc/d t = I;  d(x,y)/d pc = iz [1 0 -x; 0 1 -y]
     for (int k = 0; k < 3; ++k) {
         R.dx[k] = iz * (dRda[0 * 3 + k] - x * dRda[2 * 3 + k]);
