@@ -667,4 +667,30 @@ cba_status cba_optimize_homography(int32_t n, const double* X, const double* Y, 
     return cba_optimize_homography_batch(1, off, X, Y, u, v, h9, opts, summary, cov64);
 }
 
+cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                           const double* u, const double* v, double* kmtx5, double* c_T_t, int32_t num_radial,
+                                           const double* bounds_lo5, const double* bounds_hi5, const int32_t* fixed_idx,
+                                           const double* fixed_val, int32_t n_fixed, const cba_options* opts, cba_summary* summary,
+                                           double* distortion, double* view_errors, double* cov) {
+    return guarded([&] {
+        if (!opts || !summary) throw std::invalid_argument("null argument");
+        if (n_views < 4) {  // intrinsicssemidlt.cpp:163-166: message on stderr and a default-constructed result, no exception
+            std::memset(summary, 0, sizeof(*summary));
+            summary->termination = CBA_TERM_FAILURE;
+            std::snprintf(summary->report, sizeof(summary->report), "Insufficient views for calibration (at least 4 required).");
+            return;
+        }
+        if (!view_offset || !X || !Y || !u || !v || !kmtx5 || !c_T_t) throw std::invalid_argument("null argument");
+        if (num_radial < 0 || num_radial > 3) throw std::invalid_argument("num_radial must be in [0, 3]");
+        if ((bounds_lo5 == nullptr) != (bounds_hi5 == nullptr)) throw std::invalid_argument("bounds need both ends");
+        if (n_fixed < 0 || (n_fixed > 0 && !fixed_idx)) throw std::invalid_argument("bad fixed distortion list");
+        for (int i = 0; i < n_views; ++i)
+            if (view_offset[i + 1] < view_offset[i] || view_offset[i + 1] - view_offset[i] > 0x7fffffff)
+                throw std::invalid_argument("bad view offsets");
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        semidlt_solve(n_views, view_offset, X, Y, u, v, kmtx5, c_T_t, num_radial, bounds_lo5, bounds_hi5, fixed_idx, fixed_val, n_fixed,
+                      opts, summary, distortion, view_errors, (cov && opts->compute_covariance) ? cov : nullptr, 0);
+    });
+}
+
 }  // extern "C"

@@ -56,6 +56,20 @@ class IntrinsicsOptimOptions:  # intrinsics.h:13-20
 
 
 @dataclass
+class CalibrationBounds:  # include/calib/models/camera_matrix.h:50-72
+    fx_min: float = 0.0
+    fx_max: float = 2000.0
+    fy_min: float = 0.0
+    fy_max: float = 2000.0
+    cx_min: float = 0.0
+    cx_max: float = 1280.0
+    cy_min: float = 0.0
+    cy_max: float = 720.0
+    skew_min: float = -0.01
+    skew_max: float = 0.01
+
+
+@dataclass
 class ExtrinsicOptions:  # extrinsics.h:22-27
     core: OptimOptions = field(default_factory=OptimOptions)
     optimize_intrinsics: bool = True
@@ -85,6 +99,7 @@ class IntrinsicsOptimizationResult:  # intrinsics.h:22-28
     camera: np.ndarray
     c_se3_t: List[np.ndarray]
     view_errors: List[float] = field(default_factory=list)  # never filled by optimize_intrinsics
+    distortion: Optional[np.ndarray] = None  # optimize_intrinsics_semidlt: the fitted [k1..k_nr, p1, p2] as returned by solve_full
 
 
 @dataclass
@@ -528,3 +543,44 @@ def optimize_homography_batch(views, init_hs, options: Optional[OptimOptions] = 
 def optimize_homography(data, init_h, options: Optional[OptimOptions] = None) -> OptimizeHomographyResult:
     """optimize_homography (homography.h:17-18, homography.cpp:144-175); data rows = [x, y, u, v]."""
     return optimize_homography_batch([data], [init_h], options)[0]
+
+
+def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t, opts: Optional[IntrinsicsOptimOptions] = None,
+                                bounds: Optional[CalibrationBounds] = None, fixed_distortion_indices=(), fixed_distortion_values=()
+                                ) -> IntrinsicsOptimizationResult:
+    """optimize_intrinsics_semidlt (intrinsics.h:30-33, intrinsicssemidlt.cpp:155-191).  initial_guess = [fx, fy, cx, cy, skew].
+    init_c_se3_t: the per-view seeds the reference computes inside the call with calib::estimate_planar_pose (host code of
+    calib::estimation_linear, :37-40) — the caller (adapter) computes them and passes them in."""
+    opts = opts or IntrinsicsOptimOptions()
+    lib = capi.load_library()
+    nv = len(views)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views]
+    off = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    K = np.ascontiguousarray(np.asarray(initial_guess, dtype=np.float64).reshape(5)).copy()
+    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_c_se3_t])) if nv else np.zeros((0, 7))
+    nr = int(getattr(opts, "num_radial", 2))
+    copts = to_cba_options(opts.core, optimize_skew=opts.optimize_skew)
+    s = CbaSummary()
+    dist, ve = np.zeros(nr + 2), np.zeros(max(nv, 1))
+    dim = 5 + 7 * nv
+    cov = np.zeros((dim, dim)) if opts.core.compute_covariance else None
+    lo = hi = None
+    if bounds is not None:
+        lo = np.array([bounds.fx_min, bounds.fy_min, bounds.cx_min, bounds.cy_min, bounds.skew_min], dtype=np.float64)
+        hi = np.array([bounds.fx_max, bounds.fy_max, bounds.cx_max, bounds.cy_max, bounds.skew_max], dtype=np.float64)
+    fi = np.ascontiguousarray(list(fixed_distortion_indices), dtype=np.int32)
+    fv = np.ascontiguousarray(list(fixed_distortion_values) + [0.0] * (len(fi) - len(list(fixed_distortion_values))), dtype=np.float64)
+    capi.check(lib, lib.cba_optimize_intrinsics_semidlt(nv, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), dptr(poses), nr,
+                                                        dptr(lo), dptr(hi), i32ptr(fi) if len(fi) else i32ptr(None),
+                                                        dptr(fv) if len(fi) else dptr(None), len(fi), C.byref(copts), C.byref(s),
+                                                        dptr(dist), dptr(ve), dptr(cov)))
+    if nv < 4:  # the reference returns a default-constructed result
+        return IntrinsicsOptimizationResult(OptimResult(), np.zeros(10), [], [])
+    camera = np.concatenate([K, np.zeros(5)])
+    camera[5:5 + nr] = dist[:nr]  # BrownConrady coeffs [k1..k_nr, p1, p2] laid into the 10-vector [.., k1 k2 k3 p1 p2]
+    camera[8:10] = dist[nr:]
+    c = cov if cov is not None and np.any(cov) else None
+    return IntrinsicsOptimizationResult(result_core(s, c), camera, [pose_to_matrix(p) for p in poses], [float(e) for e in ve[:nv]], dist)

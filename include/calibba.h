@@ -21,6 +21,8 @@
  *                               (src/estimation/optim/handeye.cpp:60-78)
  *   cba_optimize_planar_pose    include/calib/estimation/optim/planarpose.h:24-26
  *                               (src/estimation/optim/planarpose.cpp:84-127)
+ *   cba_optimize_intrinsics_semidlt  include/calib/estimation/optim/intrinsics.h (optimize_intrinsics_semidlt)
+ *                               (src/estimation/optim/intrinsicssemidlt.cpp:155-191)
  *   cba_optimize_homography     include/calib/estimation/optim/homography.h:17-18
  *                               (src/estimation/optim/homography.cpp:144-175)
  *   cba_reproj_* (handle API)   the ceres::Problem the reference builds and solves inside those
@@ -272,6 +274,24 @@ cba_status cba_optimize_homography(int32_t n, const double* X, const double* Y, 
 cba_status cba_optimize_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
                                          const double* u, const double* v, double* h9 /*[n_views][9]*/,
                                          const cba_options* opts, cba_summary* summaries, double* cov64 /*[n_views][64]*/);
+
+/* optimize_intrinsics_semidlt (include/calib/estimation/optim/intrinsics.h, src/estimation/optim/intrinsicssemidlt.cpp:155-191):
+ * refinement of K = [fx, fy, cx, cy, skew] and one pose per view with the Brown-Conrady coefficients of ALL views
+ * eliminated by linear least squares inside the cost (CalibVPResidual, residuals/intrinsicsemidltresidual.h:19-73): one
+ * residual block, one Huber loss, QuaternionManifold per view, skew held by a SubsetManifold unless opts->optimize_skew,
+ * optional box bounds on K (CalibrationBounds; both pointers NULL = none).
+ * kmtx5 in/out; c_T_t [n_views][7] in/out — the reference seeds these inside the call with calib::estimate_planar_pose
+ * (host code of calib::estimation_linear, intrinsicssemidlt.cpp:37-40); the adapter calls it and passes the result.
+ * After the solve the coefficients are re-fitted with the listed entries held fixed (solve_full :74-90, distortion.h:296-363):
+ * distortion [num_radial + 2] = [k1.., p1, p2]; view_errors [n_views] = per-view RMS (:137-153);
+ * cov [(5 + 7 n_views)^2], block order [K, all quaternions, all translations], scaled by ssr / max(1, 2N - (5 + 7 n_views))
+ * (:184-188), zeros if rank deficient; may be NULL.  Fewer than 4 views: CBA_OK with summary->success = 0 and nothing written
+ * (the reference prints a message and returns a default result, :163-166). */
+cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                           const double* u, const double* v, double* kmtx5, double* c_T_t, int32_t num_radial,
+                                           const double* bounds_lo5, const double* bounds_hi5, const int32_t* fixed_distortion_indices,
+                                           const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
+                                           cba_summary* summary, double* distortion, double* view_errors, double* cov);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ struct ParamBlock {
     int subset_const = -1;          // ceres::SubsetManifold({idx}); -1 = none
     std::vector<int> lower_idx;     // indices with lower bound
     std::vector<double> lower_val;
+    std::vector<int> upper_idx;     // indices with upper bound (SetParameterUpperBound)
+    std::vector<double> upper_val;
     int toff = -1;                  // tangent offset (-1 if constant)
     int aoff = -1;                  // offset in the packed ambient state vector
     int tsize() const {
@@ -127,6 +129,10 @@ class Problem {
         params[id].lower_idx.push_back(idx);
         params[id].lower_val.push_back(v);
     }
+    void set_upper(int id, int idx, double v) {
+        params[id].upper_idx.push_back(idx);
+        params[id].upper_val.push_back(v);
+    }
 
     // ---- layout -----------------------------------------------------------
     int ntan = 0, namb = 0;
@@ -142,7 +148,7 @@ class Problem {
             if (p.constant || !used[i]) { p.toff = -1; p.aoff = -1; continue; }
             p.toff = ntan; ntan += p.tsize();
             p.aoff = namb; namb += p.size;
-            if (!p.lower_idx.empty()) constrained = true;
+            if (!p.lower_idx.empty() || !p.upper_idx.empty()) constrained = true;
         }
     }
 
@@ -188,6 +194,8 @@ class Problem {
             }
             for (size_t b = 0; b < p.lower_idx.size(); ++b)
                 o[p.lower_idx[b]] = std::max(o[p.lower_idx[b]], p.lower_val[b]);
+            for (size_t b = 0; b < p.upper_idx.size(); ++b)
+                o[p.upper_idx[b]] = std::min(o[p.upper_idx[b]], p.upper_val[b]);
         }
     }
 

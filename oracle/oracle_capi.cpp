@@ -507,3 +507,163 @@ int orc_axxb_solve(int n_pairs, const double* pairs, double* pose7, const cba_op
 }
 
 }  // extern "C"
+
+// ---- semi-DLT intrinsics (variable projection over all views) ------------------------------------
+namespace {
+struct SemiDltProblem {
+    Problem p;
+    std::vector<ViewData> views;
+    int kid = -1;
+    std::vector<int> qid, tid;
+    const CalibVPBlock* raw = nullptr;
+    SemiDltProblem(int n_views, const int64_t* off, const double* X, const double* Y, const double* u, const double* v, double* kappa5,
+                   double* poses7, int num_radial, const double* lo, const double* hi, const cba_options& o) {
+        for (int i = 0; i < n_views; ++i) {
+            ViewData vd; vd.n = static_cast<int>(off[i + 1] - off[i]);
+            vd.X = X + off[i]; vd.Y = Y + off[i]; vd.u = u + off[i]; vd.v = v + off[i];
+            views.push_back(vd);
+        }
+        // build_problem, intrinsicssemidlt.cpp:93-143
+        kid = p.add_param(kappa5, 5);
+        auto rb = std::make_unique<CalibVPBlock>(views, num_radial);
+        raw = rb.get();
+        rb->pb.push_back(kid);
+        for (int i = 0; i < n_views; ++i) {
+            qid.push_back(p.add_param(poses7 + 7 * static_cast<size_t>(i), 4, BLK_QUAT));
+            tid.push_back(p.add_param(poses7 + 7 * static_cast<size_t>(i) + 4, 3));
+            rb->pb.push_back(qid.back());
+            rb->pb.push_back(tid.back());
+        }
+        p.residuals.push_back(std::move(rb));
+        if (lo && hi)
+            for (int k = 0; k < 5; ++k) { p.set_lower(kid, k, lo[k]); p.set_upper(kid, k, hi[k]); }
+        if (!o.optimize_skew) p.params[kid].subset_const = 4;
+    }
+};
+}  // namespace
+
+extern "C" {
+// residual (2N), ambient Jacobian blocks concatenated per row [intr5 | q0(4) t0(3) | q1 t1 ...] (2N x (5 + 7V)), alpha
+int orc_semidlt_eval(int n_views, const int64_t* off, const double* X, const double* Y, const double* u, const double* v,
+                     const double* kappa5, const double* poses7, int num_radial, double* r, double* Jamb, double* alpha) {
+    return guarded([&] {
+        std::vector<double> k(kappa5, kappa5 + 5), ps(poses7, poses7 + 7 * static_cast<size_t>(n_views));
+        cba_options o; std::memset(&o, 0, sizeof(o)); o.optimize_skew = 1;
+        SemiDltProblem sp(n_views, off, X, Y, u, v, k.data(), ps.data(), num_radial, nullptr, nullptr, o);
+        const int nres = sp.raw->nres, nb = 1 + 2 * n_views, width = 5 + 7 * n_views;
+        std::vector<const double*> xp(nb);
+        std::vector<std::vector<double>> Js(nb);
+        std::vector<double*> Jp(nb);
+        xp[0] = k.data();
+        for (int i = 0; i < n_views; ++i) { xp[1 + 2 * i] = &ps[7 * static_cast<size_t>(i)]; xp[2 + 2 * i] = &ps[7 * static_cast<size_t>(i) + 4]; }
+        for (int bk = 0; bk < nb; ++bk) { const int sz = bk == 0 ? 5 : (bk % 2 == 1 ? 4 : 3); Js[bk].assign(static_cast<size_t>(nres) * sz, 0.0); Jp[bk] = Js[bk].data(); }
+        sp.raw->evaluate(xp.data(), r, Jamb ? Jp.data() : nullptr);
+        if (Jamb) {
+            int col = 0;
+            for (int bk = 0; bk < nb; ++bk) {
+                const int sz = bk == 0 ? 5 : (bk % 2 == 1 ? 4 : 3);
+                for (int i = 0; i < nres; ++i)
+                    for (int c = 0; c < sz; ++c) Jamb[static_cast<size_t>(i) * width + col + c] = Js[bk][static_cast<size_t>(i) * sz + c];
+                col += sz;
+            }
+        }
+        if (alpha) { std::vector<double> rr(nres); sp.raw->residuals<double>(xp.data(), rr.data(), alpha); }
+    });
+}
+
+// optimize_intrinsics_semidlt core (intrinsicssemidlt.cpp:155-191) with kappa5 and poses in/out:
+// distortion = solve_full with the fixed entries (:74-90), view_errors (:137-153), cov = ceres::Covariance over
+// [intr, quats, trans] * ssr / max(1, 2N - (5 + 7V)) (:184-188), zeros when rank deficient.
+int orc_semidlt_solve(int n_views, const int64_t* off, const double* X, const double* Y, const double* u, const double* v, double* kappa5,
+                      double* poses7, int num_radial, const double* lo, const double* hi, const int32_t* fixed_idx,
+                      const double* fixed_val, int n_fixed, const cba_options* o, cba_summary* out, double* distortion,
+                      double* view_errors, double* cov) {
+    return guarded([&] {
+        SemiDltProblem sp(n_views, off, X, Y, u, v, kappa5, poses7, num_radial, lo, hi, *o);
+        LMSummary s;
+        const auto t0 = std::chrono::steady_clock::now();
+        sp.p.solve(to_lm(*o, 1), &s);
+        fill_summary(s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        // solve_full: design matrix at the final point, coefficients listed in fixed_idx held at fixed_val
+        const int m = num_radial + 2, N = sp.raw->total;
+        std::vector<double> A(static_cast<size_t>(2 * N) * m), b(2 * N);
+        {
+            int row = 0;
+            for (int vi = 0; vi < n_views; ++vi) {
+                double R[9];
+                quat_to_rotmat<double>(poses7 + 7 * static_cast<size_t>(vi), R);
+                const double* t = poses7 + 7 * static_cast<size_t>(vi) + 4;
+                const ViewData& w = sp.views[vi];
+                for (int i = 0; i < w.n; ++i, row += 2) {
+                    const double pc0 = R[0] * w.X[i] + R[1] * w.Y[i] + t[0], pc1 = R[3] * w.X[i] + R[4] * w.Y[i] + t[1],
+                                 pc2 = R[6] * w.X[i] + R[7] * w.Y[i] + t[2];
+                    const double x = pc0 / pc2, y = pc1 / pc2, r2 = x * x + y * y;
+                    const double fx = kappa5[0], fy = kappa5[1], cx = kappa5[2], cy = kappa5[3], skew = kappa5[4];
+                    double* Au = &A[static_cast<size_t>(row) * m];
+                    double* Av = &A[static_cast<size_t>(row + 1) * m];
+                    double rpow = r2;
+                    for (int j = 0; j < num_radial; ++j) { Au[j] = fx * x * rpow + skew * y * rpow; Av[j] = fy * y * rpow; rpow *= r2; }
+                    Au[num_radial] = fx * (2 * x * y) + skew * (r2 + 2 * y * y);
+                    Au[num_radial + 1] = fx * (r2 + 2 * x * x) + skew * (2 * x * y);
+                    Av[num_radial] = fy * (r2 + 2 * y * y);
+                    Av[num_radial + 1] = fy * (2 * x * y);
+                    b[row] = w.u[i] - (fx * x + skew * y + cx);
+                    b[row + 1] = w.v[i] - (fy * y + cy);
+                }
+            }
+        }
+        if (N < 8) throw std::runtime_error("Failed to compute distortion parameters");
+        std::vector<double> alpha(m, 0.0);
+        std::vector<char> fixed(m, 0);
+        for (int i = 0; i < n_fixed; ++i) {
+            if (fixed_idx[i] < 0 || fixed_idx[i] >= m) throw std::invalid_argument("Fixed distortion index out of range");
+            if (!fixed[fixed_idx[i]]) { fixed[fixed_idx[i]] = 1; alpha[fixed_idx[i]] = fixed_val ? fixed_val[i] : 0.0; }
+        }
+        std::vector<int> fr;
+        for (int a = 0; a < m; ++a) if (!fixed[a]) fr.push_back(a);
+        const int nf = static_cast<int>(fr.size());
+        if (nf > 0) {
+            std::vector<double> Nf(static_cast<size_t>(nf) * nf, 0.0), bf(nf, 0.0);
+            for (int rw = 0; rw < 2 * N; ++rw) {
+                double badj = b[rw];
+                for (int a = 0; a < m; ++a) if (fixed[a]) badj -= A[static_cast<size_t>(rw) * m + a] * alpha[a];
+                for (int i = 0; i < nf; ++i) {
+                    bf[i] += A[static_cast<size_t>(rw) * m + fr[i]] * badj;
+                    for (int j = 0; j < nf; ++j) Nf[static_cast<size_t>(i) * nf + j] += A[static_cast<size_t>(rw) * m + fr[i]] * A[static_cast<size_t>(rw) * m + fr[j]];
+                }
+            }
+            if (!cholesky_inplace(Nf, nf)) throw std::runtime_error("Failed to compute distortion parameters");
+            cholesky_solve(Nf, nf, bf);
+            for (int i = 0; i < nf; ++i) alpha[fr[i]] = bf[i];
+        }
+        double ssr = 0;
+        {
+            int row = 0;
+            for (int vi = 0; vi < n_views; ++vi) {
+                double sv = 0;
+                for (int i = 0; i < 2 * sp.views[vi].n; ++i, ++row) {
+                    double rr = -b[row];
+                    for (int a = 0; a < m; ++a) rr += A[static_cast<size_t>(row) * m + a] * alpha[a];
+                    sv += rr * rr;
+                }
+                ssr += sv;
+                if (view_errors) view_errors[vi] = std::sqrt(sv / (2.0 * sp.views[vi].n));
+            }
+        }
+        if (distortion) for (int a = 0; a < m; ++a) distortion[a] = alpha[a];
+        if (cov) {
+            const size_t dim = 5 + 7 * static_cast<size_t>(n_views);
+            std::memset(cov, 0, sizeof(double) * dim * dim);
+            std::vector<int> order{sp.kid};
+            for (int id : sp.qid) order.push_back(id);
+            for (int id : sp.tid) order.push_back(id);
+            std::vector<double> c; int d = 0;
+            if (sp.p.covariance(to_lm(*o, 1), order, &c, &d)) {
+                const double vf = ssr / std::max(1, 2 * N - static_cast<int>(dim));
+                for (size_t k = 0; k < dim * dim; ++k) cov[k] = c[k] * vf;
+            }
+        }
+    });
+}
+}  // extern "C"
+

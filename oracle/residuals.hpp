@@ -6,6 +6,7 @@
 // bundleresidual.h:58-68) and one 6-residual block per motion pair
 // (handeyeresidual.h:51-53).
 #pragma once
+#include <limits>
 #include <stdexcept>
 #include <vector>
 
@@ -217,6 +218,122 @@ struct PlanarPoseVPBlock final : ResidualBlock {
         for (int i = 0; i < nres; ++i) {
             r[i] = rj[i].a;
             if (J[0]) for (int k = 0; k < 6; ++k) J[0][static_cast<size_t>(i) * 6 + k] = rj[i].v[k];
+        }
+    }
+};
+
+// CalibVPResidual::operator(), src/estimation/residuals/intrinsicsemidltresidual.h:34-58: parameter blocks
+// [intr(5) | quat_0(4) tran_0(3) | quat_1 tran_1 | ...]; every view's points go through
+// planar_observables_to_observables (observationutils.h:78-95: point = c_se3_t * (X, Y, 0), xn = x/z, yn = y/z with the
+// rotation from quat_array_to_rotmat, no normalisation), then ONE fit_distortion_full over all observations
+// (distortion.h:229-295) and residual = A alpha - b.  Least squares by normal equations on Jets, as in PlanarPoseVPBlock.
+// Jets are NJ = 5 + 7 * VMAX wide: the oracle handles up to VMAX views (enough for the tests).
+struct CalibVPBlock final : ResidualBlock {
+    static constexpr int VMAX = 6, NJ = 5 + 7 * VMAX;
+    std::vector<ViewData> views;
+    int num_radial, total = 0;
+    CalibVPBlock(const std::vector<ViewData>& v, int nr) : views(v), num_radial(nr) {
+        if (static_cast<int>(v.size()) > VMAX) throw std::invalid_argument("oracle CalibVPBlock: too many views for the fixed Jet width");
+        for (const auto& w : v) total += w.n;
+        nres = 2 * total;
+    }
+    // p[0] = intr5, p[1 + 2 i] = quat_i, p[2 + 2 i] = tran_i.  Returns false when fit_distortion_full would (N < 8).
+    template <typename T>
+    bool residuals(const T* const* p, T* r, T* alpha_out) const {
+        const int m = num_radial + 2, N = total;
+        if (N < 8) return false;  // distortion.h:235-238
+        const T fx = p[0][0], fy = p[0][1], cx = p[0][2], cy = p[0][3], skew = p[0][4];
+        std::vector<T> A(static_cast<size_t>(2 * N) * m), b(2 * N);
+        int row = 0;
+        for (size_t vi = 0; vi < views.size(); ++vi) {
+            T R[9];
+            quat_to_rotmat<T>(p[1 + 2 * vi], R);
+            const T* t = p[2 + 2 * vi];
+            const ViewData& view = views[vi];
+            for (int i = 0; i < view.n; ++i, row += 2) {
+                const T X(view.X[i]), Y(view.Y[i]);
+                const T pc0 = R[0] * X + R[1] * Y + t[0], pc1 = R[3] * X + R[4] * Y + t[1], pc2 = R[6] * X + R[7] * Y + t[2];
+                const T x = pc0 / pc2, y = pc1 / pc2;
+                const T r2 = x * x + y * y;
+                T* Au = &A[static_cast<size_t>(row) * m];
+                T* Av = &A[static_cast<size_t>(row + 1) * m];
+                T rpow = r2;
+                for (int j = 0; j < num_radial; ++j) {
+                    Au[j] = fx * x * rpow + skew * y * rpow;
+                    Av[j] = fy * y * rpow;
+                    rpow = rpow * r2;
+                }
+                Au[num_radial] = fx * (T(2.0) * x * y) + skew * (r2 + T(2.0) * y * y);
+                Au[num_radial + 1] = fx * (r2 + T(2.0) * x * x) + skew * (T(2.0) * x * y);
+                Av[num_radial] = fy * (r2 + T(2.0) * y * y);
+                Av[num_radial + 1] = fy * (T(2.0) * x * y);
+                b[row] = T(view.u[i]) - (fx * x + skew * y + cx);
+                b[row + 1] = T(view.v[i]) - (fy * y + cy);
+            }
+        }
+        std::vector<T> M(static_cast<size_t>(m) * m, T(0.0)), rhs(m, T(0.0)), L(static_cast<size_t>(m) * m, T(0.0)), al(m);
+        for (int rw = 0; rw < 2 * N; ++rw)
+            for (int a = 0; a < m; ++a) {
+                rhs[a] = rhs[a] + A[static_cast<size_t>(rw) * m + a] * b[rw];
+                for (int c = 0; c <= a; ++c) M[a * m + c] = M[a * m + c] + A[static_cast<size_t>(rw) * m + a] * A[static_cast<size_t>(rw) * m + c];
+            }
+        for (int j = 0; j < m; ++j) {
+            T d = M[j * m + j];
+            for (int k = 0; k < j; ++k) d = d - L[j * m + k] * L[j * m + k];
+            d = sqrt(d);
+            L[j * m + j] = d;
+            for (int i = j + 1; i < m; ++i) {
+                T sacc = M[i * m + j];
+                for (int k = 0; k < j; ++k) sacc = sacc - L[i * m + k] * L[j * m + k];
+                L[i * m + j] = sacc / d;
+            }
+        }
+        for (int i = 0; i < m; ++i) {
+            T sacc = rhs[i];
+            for (int k = 0; k < i; ++k) sacc = sacc - L[i * m + k] * al[k];
+            al[i] = sacc / L[i * m + i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+            T sacc = al[i];
+            for (int k = i + 1; k < m; ++k) sacc = sacc - L[k * m + i] * al[k];
+            al[i] = sacc / L[i * m + i];
+        }
+        for (int rw = 0; rw < 2 * N; ++rw) {
+            T sacc = -b[rw];
+            for (int a = 0; a < m; ++a) sacc = sacc + A[static_cast<size_t>(rw) * m + a] * al[a];
+            r[rw] = sacc;
+        }
+        if (alpha_out)
+            for (int a = 0; a < m; ++a) alpha_out[a] = al[a];
+        return true;
+    }
+    void evaluate(const double* const* x, double* r, double** J) const override {
+        const int nb = 1 + 2 * static_cast<int>(views.size());
+        if (!J) {
+            if (!residuals<double>(x, r, nullptr))
+                for (int i = 0; i < nres; ++i) r[i] = std::numeric_limits<double>::quiet_NaN();
+            return;
+        }
+        using JT = Jet<NJ>;
+        std::vector<std::vector<JT>> store(nb);
+        std::vector<const JT*> ptr(nb);
+        int col = 0;
+        for (int bk = 0; bk < nb; ++bk) {
+            const int sz = bk == 0 ? 5 : (bk % 2 == 1 ? 4 : 3);
+            store[bk].resize(sz);
+            for (int k = 0; k < sz; ++k) store[bk][k] = JT(x[bk][k], col++);
+            ptr[bk] = store[bk].data();
+        }
+        std::vector<JT> rj(nres);
+        const bool ok = residuals<JT>(ptr.data(), rj.data(), nullptr);
+        col = 0;
+        for (int bk = 0; bk < nb; ++bk) {
+            const int sz = bk == 0 ? 5 : (bk % 2 == 1 ? 4 : 3);
+            for (int i = 0; i < nres; ++i) {
+                if (bk == 0) r[i] = ok ? rj[i].a : std::numeric_limits<double>::quiet_NaN();
+                if (J[bk]) for (int k = 0; k < sz; ++k) J[bk][static_cast<size_t>(i) * sz + k] = ok ? rj[i].v[col + k] : 0.0;
+            }
+            col += sz;
         }
     }
 };

@@ -17,6 +17,13 @@ PO = C.POINTER(CbaOptions)
 PS = C.POINTER(CbaSummary)
 
 
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+# (n_views, off, X, Y, u, v, kappa5, poses7, num_radial, lo5, hi5, fixed_idx, fixed_val, n_fixed, opts, summary, distortion, view_errors, cov)
+SEMIDLT_SOLVE_ARGS = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p,
+                      c_double_p, c_int32_p, c_double_p, C.c_int, PO, PS, c_double_p, c_double_p, c_double_p]
+
+
 def load_oracle():
     o = C.CDLL(ORACLE_SO)
     o.orc_last_error.restype = C.c_char_p
@@ -40,6 +47,9 @@ def load_oracle():
     o.orc_homography_eval.argtypes = [c_double_p, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p]
     o.orc_homography_eval.restype = None
     o.orc_homography_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
+    o.orc_semidlt_eval.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,
+                                   c_double_p, c_double_p, c_double_p]
+    o.orc_semidlt_solve.argtypes = SEMIDLT_SOLVE_ARGS
     o.orc_quat_to_rotmat.argtypes = [c_double_p, c_double_p]
     o.orc_rotmat_to_quat.argtypes = [c_double_p, c_double_p]
     o.orc_quat_plus.argtypes = [c_double_p, c_double_p, c_double_p]
@@ -61,6 +71,12 @@ def load_hostmath():
     h.hm_homography_eval.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, c_double_p,
                                      c_double_p, c_double_p]
     h.hm_homography_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
+    h.hm_semidlt_last_error.restype = C.c_char_p
+    h.hm_semidlt_linearise.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, PO,
+                                       c_double_p, c_double_p, c_double_p, c_double_p]
+    h.hm_semidlt_step.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, PO,
+                                  c_double_p, c_double_p]
+    h.hm_semidlt_solve.argtypes = SEMIDLT_SOLVE_ARGS
     h.hm_quat_to_angle_axis.argtypes = [c_double_p, c_double_p]
     h.hm_angle_axis_to_quat.argtypes = [c_double_p, c_double_p]
     h.hm_handeye_last_error.restype = C.c_char_p
@@ -300,3 +316,47 @@ def dlt_homography(view):
 def is_approx(a, b, tol):
     """Eigen's isApprox: |a - b|_F <= tol * min(|a|_F, |b|_F)."""
     return np.linalg.norm(a - b) <= tol * min(np.linalg.norm(a), np.linalg.norm(b))
+
+
+# ---- semi-DLT intrinsics (intrinsicssemidlt.cpp; the reference has no test of its own for this entry point) -------------
+def semidlt_scene(n_views=5, rows=6, cols=7, noise=0.0, seed=3, nr=2):
+    """Views of a rows x cols grid through a pinhole + Brown-Conrady camera whose coefficients beyond num_radial are zero, so
+    the variable-projection model is exact: returns (flat problem with perturbed K / poses, K_gt(5), alpha_gt(nr + 2))."""
+    from calibration_amd import synth
+
+    sc = synth.scene_intrinsics(n_views, rows=rows, cols=cols, spacing=0.08, noise_px=noise, seed=seed)
+    cam = sc.gt_intr.reshape(-1).copy()
+    radial = cam[5:8].copy()
+    radial[nr:] = 0.0
+    cam[5:8] = radial
+    rng = np.random.default_rng(seed + 1)
+    grid = synth.make_target_grid(rows, cols, 0.08)
+    views = []
+    for p in sc.gt_view_pose:
+        from calibration_amd.geometry import pose_to_matrix
+
+        views.append(synth.render_view(cam, pose_to_matrix(p), grid, noise, rng, cull=False))
+    off = np.zeros(n_views + 1, dtype=np.int64)
+    np.cumsum([len(v) for v in views], out=off[1:])
+    allv = np.concatenate(views)
+    data = dict(off=off, X=np.ascontiguousarray(allv[:, 0]), Y=np.ascontiguousarray(allv[:, 1]), u=np.ascontiguousarray(allv[:, 2]),
+                v=np.ascontiguousarray(allv[:, 3]), kappa0=np.ascontiguousarray(sc.flat.intr.reshape(-1)[:5].copy()),
+                poses0=np.ascontiguousarray(sc.flat.view_pose.copy()), poses_gt=sc.gt_view_pose.copy(), n_views=n_views)
+    alpha_gt = np.concatenate([cam[5:5 + nr], cam[8:10]])
+    return data, cam[:5].copy(), alpha_gt
+
+
+def semidlt_solve(fn, d, nr, o, lo=None, hi=None, fixed=None, want_cov=True):
+    """Calls a *_semidlt_solve entry point (oracle / host build / C ABI have the same argument list)."""
+    k, p = d["kappa0"].copy(), d["poses0"].copy()
+    V = d["n_views"]
+    s, dist, ve = CbaSummary(), np.zeros(nr + 2), np.zeros(V)
+    cov = np.zeros((5 + 7 * V, 5 + 7 * V))
+    fi = None if not fixed else np.ascontiguousarray([f[0] for f in fixed], dtype=np.int32)
+    fv = None if not fixed else np.ascontiguousarray([f[1] for f in fixed], dtype=np.float64)
+    st = fn(V, d["off"].ctypes.data_as(c_int64_p), capi.dptr(d["X"]), capi.dptr(d["Y"]), capi.dptr(d["u"]), capi.dptr(d["v"]), capi.dptr(k),
+            capi.dptr(p), nr, capi.dptr(None if lo is None else np.ascontiguousarray(lo, dtype=float)),
+            capi.dptr(None if hi is None else np.ascontiguousarray(hi, dtype=float)),
+            None if fi is None else fi.ctypes.data_as(c_int32_p), capi.dptr(fv), 0 if not fixed else len(fixed), C.byref(o), C.byref(s),
+            capi.dptr(dist), capi.dptr(ve), capi.dptr(cov if want_cov else None))
+    return st, k, p, s, dist, ve, cov

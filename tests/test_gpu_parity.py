@@ -486,3 +486,52 @@ def test_homography_batch_matches_oracle(gpu_lib, oracle):
             assert abs(s.final_cost - r.core.final_cost) <= 1e-9 * max(1.0, s.final_cost)
             if np.any(cov) and r.core.covariance is not None and s.final_cost > 1e-12:
                 assert np.abs(cov - r.core.covariance).max() <= 1e-6 * np.abs(cov).max()
+
+
+# ---- optimize_intrinsics_semidlt: per-view wave kernels + host arrow/Woodbury LM ---------------------------------------------
+@pytest.mark.parametrize("case", [dict(nr=2, noise=0.0), dict(nr=2, noise=0.2), dict(nr=3, noise=0.2, okw=dict(optimize_skew=1)),
+                                  dict(nr=2, noise=0.2, bounds=True), dict(nr=2, noise=0.2, fixed=[(1, 0.0)]), dict(nr=0, noise=0.2),
+                                  dict(nr=1, noise=0.2, okw=dict(huber_delta=-1.0))])
+def test_semidlt_gpu_matches_oracle(gpu_lib, oracle, case):
+    nr = case["nr"]
+    d, kgt, agt = helpers.semidlt_scene(5, noise=case["noise"], nr=nr)
+    o = options(epsilon=1e-12, **case.get("okw", {}))
+    lo, hi = (None, None)
+    if case.get("bounds"):
+        lo, hi = [kgt[0] - 200, kgt[1] - 200, kgt[2] - 30, kgt[3] - 30, -0.01], [kgt[0] + 200, kgt[1] - 25.0, kgt[2] + 30, kgt[3] + 30, 0.01]
+    gpu_lib.cba_optimize_intrinsics_semidlt.argtypes = helpers.SEMIDLT_SOLVE_ARGS
+    sta, ka, pa, sa, da, va, ca = helpers.semidlt_solve(oracle.orc_semidlt_solve, d, nr, o, lo, hi, case.get("fixed"))
+    stb, kb, pb, sb, db, vb, cb = helpers.semidlt_solve(gpu_lib.cba_optimize_intrinsics_semidlt, d, nr, o, lo, hi, case.get("fixed"))
+    assert sta == 0 and stb == 0
+    assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and abs(sa.iterations - sb.iterations) <= 2
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost)
+    assert np.abs(ka - kb).max() <= 1e-7 * np.abs(ka).max() and np.abs(pa - pb).max() <= 1e-8
+    assert np.abs(da - db).max() <= 1e-7 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-8
+    if case["noise"] > 0:
+        dg = np.sqrt(np.abs(np.diag(ca)))
+        nz = dg > 0
+        assert np.any(nz) and (np.abs(ca - cb)[np.ix_(nz, nz)] / np.outer(dg[nz], dg[nz])).max() <= 1e-5
+    else:
+        assert np.abs(kb[:4] - kgt[:4]).max() <= 1e-6 and np.abs(db - agt).max() <= 1e-7 and vb.max() <= 1e-8
+
+
+def test_semidlt_mirror_api_and_large_problem(gpu_lib):
+    """Through the mirror of the reference signature: ground-truth recovery on 60 views x 900 points (a size the Jet oracle cannot
+    hold), the < 4 views contract (default result, no exception: intrinsicssemidlt.cpp:163-166) and active bounds."""
+    from calibration_amd.geometry import pose_to_matrix
+
+    d, kgt, agt = helpers.semidlt_scene(60, rows=30, cols=30, noise=0.0, nr=2, seed=11)
+    views = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][:-1], d["off"][1:])]
+    seeds = [pose_to_matrix(p) for p in d["poses0"]]
+    opt = optim.IntrinsicsOptimOptions(core=optim.OptimOptions(epsilon=1e-12, compute_covariance=False), num_radial=2)
+    r = optim.optimize_intrinsics_semidlt(views, d["kappa0"], seeds, opt)
+    assert r.core.success, r.core.report
+    assert np.abs(r.camera[:4] - kgt[:4]).max() <= 1e-6 and np.abs(r.distortion - agt).max() <= 1e-7
+    assert max(r.view_errors) <= 1e-8 and len(r.c_se3_t) == 60
+    for T, pg in zip(r.c_se3_t, d["poses_gt"]):
+        assert np.abs(T - pose_to_matrix(pg)).max() <= 1e-7
+    few = optim.optimize_intrinsics_semidlt(views[:3], d["kappa0"], seeds[:3], opt)
+    assert not few.core.success and few.c_se3_t == []
+    b = optim.CalibrationBounds(fx_max=kgt[0] - 10.0, fy_max=2000.0, cx_max=1280.0, cy_max=720.0)
+    rb = optim.optimize_intrinsics_semidlt(views, d["kappa0"], seeds, opt, bounds=b)
+    assert rb.camera[0] == kgt[0] - 10.0

@@ -385,3 +385,93 @@ def test_homography_lm_matches_oracle(oracle, hostmath, n, noise, outliers, delt
         assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
     if outliers == 0 or delta > 0:
         assert helpers.is_approx(hb.reshape(3, 3), H, 1e-2)
+
+
+# ---- semi-DLT intrinsics: Golub-Pereyra normal equations, arrow + Woodbury step, LM vs the oracle's Jets --------------------
+def _tangent_J(Jamb, poses, V, optimize_skew):
+    """ambient [intr5 | q t | q t ...] -> tangent [kappa (4|5) | delta t | ...] via ceres' QuaternionManifold PlusJacobian"""
+    cols = [Jamb[:, :5] if optimize_skew else Jamb[:, :4]]
+    for i in range(V):
+        q = poses[i, :4]
+        PJ = np.array([[-q[1], -q[2], -q[3]], [q[0], q[3], -q[2]], [-q[3], q[0], q[1]], [q[2], -q[1], q[0]]])
+        cols.append(Jamb[:, 5 + 7 * i:9 + 7 * i] @ PJ)
+        cols.append(Jamb[:, 9 + 7 * i:12 + 7 * i])
+    return np.concatenate(cols, axis=1)
+
+
+@pytest.mark.parametrize("nr,skew,delta", [(2, 0, 1.0), (3, 1, -1.0), (1, 0, 1.0), (0, 1, 1.0)])
+def test_semidlt_normal_equations_match_oracle_jets(oracle, hostmath, nr, skew, delta):
+    d, _, _ = helpers.semidlt_scene(5, noise=0.3, nr=nr)
+    V = d["n_views"]
+    i64 = lambda a: a.ctypes.data_as(helpers.c_int64_p)  # noqa: E731
+    N = int(d["off"][-1])
+    r, J, al0 = np.zeros(2 * N), np.zeros((2 * N, 5 + 7 * V)), np.zeros(nr + 2)
+    assert oracle.orc_semidlt_eval(V, i64(d["off"]), dptr(d["X"]), dptr(d["Y"]), dptr(d["u"]), dptr(d["v"]), dptr(d["kappa0"]), dptr(d["poses0"]),
+                                   nr, dptr(r), dptr(J), dptr(al0)) == 0
+    Jt = _tangent_J(J, d["poses0"], V, skew)
+    s = float(r @ r)
+    w = delta / np.sqrt(s) if delta > 0 and s > delta * delta else 1.0
+    cost = 0.5 * ((2 * delta * np.sqrt(s) - delta * delta) if delta > 0 and s > delta * delta else s)
+    n = Jt.shape[1]
+    H, g, c, al = np.zeros((n, n)), np.zeros(n), C.c_double(), np.zeros(nr + 2)
+    o = options(optimize_skew=skew, huber_delta=delta)
+    assert hostmath.hm_semidlt_linearise(V, i64(d["off"]), dptr(d["X"]), dptr(d["Y"]), dptr(d["u"]), dptr(d["v"]), dptr(d["kappa0"]),
+                                         dptr(d["poses0"]), nr, C.byref(o), dptr(H), dptr(g), C.byref(c), dptr(al)) == 0
+    He, ge = w * Jt.T @ Jt, w * Jt.T @ r
+    assert np.abs(al - al0).max() <= 1e-9 * max(1.0, np.abs(al0).max())
+    assert abs(c.value - cost) <= 1e-10 * cost
+    assert np.abs(g - ge).max() <= 1e-8 * np.abs(ge).max()
+    sc = np.sqrt(np.outer(np.diag(He), np.diag(He)))
+    assert (np.abs(H - He) / sc).max() <= 1e-8
+    # the O(V) arrow + Woodbury solve against a dense solve of the same damped system
+    dlm = np.ascontiguousarray(1e-3 * np.diag(He) + 1e-6)
+    delta_w = np.zeros(n)
+    assert hostmath.hm_semidlt_step(V, i64(d["off"]), dptr(d["X"]), dptr(d["Y"]), dptr(d["u"]), dptr(d["v"]), dptr(d["kappa0"]), dptr(d["poses0"]),
+                                    nr, C.byref(o), dptr(dlm), dptr(delta_w)) == 0
+    delta_d = -np.linalg.solve(H + np.diag(dlm), g)
+    assert np.abs(delta_w - delta_d).max() <= 1e-7 * np.abs(delta_d).max()
+
+
+SEMIDLT_CASES = [
+    dict(nr=2, noise=0.0, okw={}),
+    dict(nr=2, noise=0.2, okw={}),
+    dict(nr=3, noise=0.2, okw=dict(optimize_skew=1)),
+    dict(nr=2, noise=0.2, okw=dict(huber_delta=-1.0)),
+    dict(nr=2, noise=0.2, okw={}, bounds=True),
+    dict(nr=2, noise=0.2, okw={}, fixed=[(1, 0.0)]),
+    dict(nr=1, noise=0.2, okw={}),
+]
+
+
+def _semidlt_bounds(kgt):
+    # the upper bound on fy is ACTIVE at the solution (the noisy 5-view minimiser sits at fy ~ 985.6)
+    return [kgt[0] - 200, kgt[1] - 200, kgt[2] - 30, kgt[3] - 30, -0.01], [kgt[0] + 200, kgt[1] - 25.0, kgt[2] + 30, kgt[3] + 30, 0.01]
+
+
+@pytest.mark.parametrize("case", SEMIDLT_CASES)
+def test_semidlt_lm_matches_oracle(oracle, hostmath, case):
+    nr = case["nr"]
+    d, kgt, agt = helpers.semidlt_scene(5, noise=case["noise"], nr=nr)
+    o = options(epsilon=1e-12, **case["okw"])
+    lo, hi = _semidlt_bounds(kgt) if case.get("bounds") else (None, None)
+    res = {}
+    for name, fn in (("oracle", oracle.orc_semidlt_solve), ("product", hostmath.hm_semidlt_solve)):
+        res[name] = helpers.semidlt_solve(fn, d, nr, o, lo, hi, case.get("fixed"))
+        assert res[name][0] == 0
+    (_, ka, pa, sa, da, va, ca), (_, kb, pb, sb, db, vb, cb) = res["oracle"], res["product"]
+    assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and abs(sa.iterations - sb.iterations) <= 2
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost)
+    assert np.abs(ka - kb).max() <= 1e-7 * np.abs(ka).max()
+    assert np.abs(pa - pb).max() <= 1e-8
+    assert np.abs(da - db).max() <= 1e-7 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-8
+    if case["noise"] > 0:
+        assert np.any(ca) and np.any(cb)
+        dg = np.sqrt(np.abs(np.diag(ca)))
+        nz = dg > 0
+        assert (np.abs(ca - cb)[np.ix_(nz, nz)] / np.outer(dg[nz], dg[nz])).max() <= 1e-5
+    if case["noise"] == 0.0:  # ground-truth recovery (the reference holds no test for this entry point; same bar as intrinsics_optimize_test)
+        assert np.abs(kb[:4] - kgt[:4]).max() <= 1e-6 and np.abs(db - agt).max() <= 1e-7 and vb.max() <= 1e-8
+    if case.get("bounds"):
+        assert kb[1] == hi[1] == ka[1]
+    if case.get("fixed"):
+        assert db[1] == 0.0
