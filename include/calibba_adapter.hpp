@@ -10,14 +10,18 @@
 //   calib::optimize_extrinsics<CameraT>                    src/estimation/optim/extrinsics.cpp:174-196
 //   calib::optimize_bundle<CameraT>                        src/estimation/optim/bundle.cpp:147-170
 //   calib::optimize_handeye                                src/estimation/optim/handeye.cpp:60-78
+//   calib::optimize_intrinsics_semidlt                     src/estimation/optim/intrinsicssemidlt.cpp:155-191
 //   calib::optimize_planar_pose                            src/estimation/optim/planarpose.cpp:84-127
 //   calib::optimize_homography                             src/estimation/optim/homography.cpp:144-175
 #pragma once
 #include <Eigen/Geometry>
 #include <array>
+#include <cstdint>
+#include <iostream>
 #include <stdexcept>
 #include <vector>
 
+#include "calib/estimation/linear/planarpose.h"
 #include "calib/estimation/optim/bundle.h"
 #include "calib/estimation/optim/extrinsics.h"
 #include "calib/estimation/optim/handeye.h"
@@ -228,6 +232,50 @@ inline void flatten_view(const calib::PlanarView& view, std::vector<double>& X, 
         X.push_back(ob.object_xy.x()); Y.push_back(ob.object_xy.y());
         u.push_back(ob.image_uv.x()); v.push_back(ob.image_uv.y());
     }
+}
+
+inline auto optimize_intrinsics_semidlt(const std::vector<calib::PlanarView>& views, const calib::CameraMatrix& initial_guess,
+                                        const calib::IntrinsicsOptimOptions& opts = {})
+    -> calib::IntrinsicsOptimizationResult<calib::PinholeCamera<calib::BrownConradyd>> {
+    calib::IntrinsicsOptimizationResult<calib::PinholeCamera<calib::BrownConradyd>> res;
+    if (views.size() < 4) {  // intrinsicssemidlt.cpp:163-166
+        std::cerr << "Insufficient views for calibration (at least 4 required)." << '\n';
+        return res;
+    }
+    std::vector<int64_t> off{0};
+    std::vector<double> X, Y, u, v, poses(7 * views.size());
+    for (size_t i = 0; i < views.size(); ++i) {
+        flatten_view(views[i], X, Y, u, v);
+        off.push_back(static_cast<int64_t>(X.size()));
+        pose_in(calib::estimate_planar_pose(views[i], initial_guess), &poses[7 * i]);  // IntrinsicBlocks::create, :37-40 (host seed)
+    }
+    double K[5] = {initial_guess.fx, initial_guess.fy, initial_guess.cx, initial_guess.cy, initial_guess.skew};
+    double lo[5], hi[5];
+    if (opts.bounds.has_value()) {
+        const auto& b = *opts.bounds;
+        const double l[5] = {b.fx_min, b.fy_min, b.cx_min, b.cy_min, b.skew_min}, h[5] = {b.fx_max, b.fy_max, b.cx_max, b.cy_max, b.skew_max};
+        for (int k = 0; k < 5; ++k) { lo[k] = l[k]; hi[k] = h[k]; }
+    }
+    std::vector<int32_t> fidx(opts.fixed_distortion_indices.begin(), opts.fixed_distortion_indices.end());
+    std::vector<double> fval(fidx.size(), 0.0);
+    for (size_t i = 0; i < fidx.size() && i < opts.fixed_distortion_values.size(); ++i) fval[i] = opts.fixed_distortion_values[i];
+    cba_options o = make_options(opts.core);
+    o.optimize_skew = opts.optimize_skew;
+    o.compute_covariance = 1;  // the reference computes it unconditionally (:184-188)
+    cba_summary sum{};
+    const Eigen::Index dim = static_cast<Eigen::Index>(5 + 7 * views.size());
+    std::vector<double> dist(static_cast<size_t>(opts.num_radial) + 2), verr(views.size()), cov(static_cast<size_t>(dim * dim));
+    check(cba_optimize_intrinsics_semidlt(static_cast<int32_t>(views.size()), off.data(), X.data(), Y.data(), u.data(), v.data(), K,
+                                          poses.data(), opts.num_radial, opts.bounds ? lo : nullptr, opts.bounds ? hi : nullptr,
+                                          fidx.empty() ? nullptr : fidx.data(), fval.empty() ? nullptr : fval.data(),
+                                          static_cast<int32_t>(fidx.size()), &o, &sum, dist.data(), verr.data(), cov.data()));
+    res.camera.kmtx.fx = K[0]; res.camera.kmtx.fy = K[1]; res.camera.kmtx.cx = K[2]; res.camera.kmtx.cy = K[3]; res.camera.kmtx.skew = K[4];
+    res.camera.distortion.coeffs = Eigen::Map<const Eigen::VectorXd>(dist.data(), static_cast<Eigen::Index>(dist.size()));
+    res.c_se3_t.resize(views.size());
+    for (size_t i = 0; i < views.size(); ++i) res.c_se3_t[i] = pose_out(&poses[7 * i]);
+    res.view_errors = verr;
+    fill_core(sum, o, cov, dim, res.core);
+    return res;
 }
 
 inline auto optimize_planar_pose(const calib::PlanarView& view, const calib::CameraMatrix& intrinsics,
