@@ -545,12 +545,12 @@ def optimize_homography(data, init_h, options: Optional[OptimOptions] = None) ->
     return optimize_homography_batch([data], [init_h], options)[0]
 
 
-def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t, opts: Optional[IntrinsicsOptimOptions] = None,
+def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t=None, opts: Optional[IntrinsicsOptimOptions] = None,
                                 bounds: Optional[CalibrationBounds] = None, fixed_distortion_indices=(), fixed_distortion_values=()
                                 ) -> IntrinsicsOptimizationResult:
     """optimize_intrinsics_semidlt (intrinsics.h:30-33, intrinsicssemidlt.cpp:155-191).  initial_guess = [fx, fy, cx, cy, skew].
-    init_c_se3_t: the per-view seeds the reference computes inside the call with calib::estimate_planar_pose (host code of
-    calib::estimation_linear, :37-40) — the caller (adapter) computes them and passes them in."""
+    init_c_se3_t: the per-view seeds the reference computes inside the call with calib::estimate_planar_pose (:37-40);
+    None = compute them the same way with the batched GPU seed (cba_estimate_planar_pose_batch)."""
     opts = opts or IntrinsicsOptimOptions()
     lib = capi.load_library()
     nv = len(views)
@@ -560,8 +560,10 @@ def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t, opts: Option
     allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
     X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
     K = np.ascontiguousarray(np.asarray(initial_guess, dtype=np.float64).reshape(5)).copy()
-    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_c_se3_t])) if nv else np.zeros((0, 7))
+    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_c_se3_t])) if nv and init_c_se3_t is not None else np.zeros((max(nv, 1), 7))
     nr = int(getattr(opts, "num_radial", 2))
+    if init_c_se3_t is None and nv >= 4:  # IntrinsicBlocks::create (:37-40): the batched GPU seed
+        poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in estimate_planar_pose_batch(views, K)]))
     copts = to_cba_options(opts.core, optimize_skew=opts.optimize_skew)
     s = CbaSummary()
     dist, ve = np.zeros(nr + 2), np.zeros(max(nv, 1))
@@ -584,3 +586,18 @@ def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t, opts: Option
     camera[8:10] = dist[nr:]
     c = cov if cov is not None and np.any(cov) else None
     return IntrinsicsOptimizationResult(result_core(s, c), camera, [pose_to_matrix(p) for p in poses], [float(e) for e in ve[:nv]], dist)
+
+
+def estimate_planar_pose_batch(views, intrinsics) -> List[np.ndarray]:
+    """Batched estimate_planar_pose (linear/planarpose.h, planarpose_linear.cpp:54-76) on the GPU: one 4x4 c_T_t per view."""
+    lib = capi.load_library()
+    nv = len(views)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views]
+    off = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    K = np.ascontiguousarray(np.asarray(intrinsics, dtype=np.float64).reshape(-1)[:5]).copy()
+    poses = np.zeros((max(nv, 1), 7))
+    capi.check(lib, lib.cba_estimate_planar_pose_batch(nv, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), dptr(poses)))
+    return [pose_to_matrix(p) for p in poses[:nv]]

@@ -293,6 +293,14 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
                                            const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
                                            cba_summary* summary, double* distortion, double* view_errors, double* cov);
 
+/* estimate_planar_pose (include/calib/estimation/linear/planarpose.h:38-110, src/estimation/linear/planarpose_linear.cpp:54-76)
+ * for a batch of views in one launch: pixels normalised by K = [fx, fy, cx, cy, skew], Hartley-normalised DLT homography
+ * (src/estimation/linear/homographyestimator.cpp:17-87), pose_from_homography_normalized (planarpose_linear.cpp:17-52).
+ * pose7 [n_views][7] out; a view with fewer than 4 points gets the identity, as in the reference (:55-57).
+ * This is the seed optimize_intrinsics' callers and optimize_intrinsics_semidlt (intrinsicssemidlt.cpp:37-40) start from. */
+cba_status cba_estimate_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                          const double* u, const double* v, const double* kmtx5, double* pose7);
+
 #ifdef __cplusplus
 }
 #endif

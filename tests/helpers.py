@@ -77,6 +77,8 @@ def load_hostmath():
     h.hm_semidlt_step.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, PO,
                                   c_double_p, c_double_p]
     h.hm_semidlt_solve.argtypes = SEMIDLT_SOLVE_ARGS
+    h.hm_planar_seed.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    h.hm_planar_seed.restype = None
     h.hm_quat_to_angle_axis.argtypes = [c_double_p, c_double_p]
     h.hm_angle_axis_to_quat.argtypes = [c_double_p, c_double_p]
     h.hm_handeye_last_error.restype = C.c_char_p

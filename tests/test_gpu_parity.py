@@ -535,3 +535,27 @@ def test_semidlt_mirror_api_and_large_problem(gpu_lib):
     b = optim.CalibrationBounds(fx_max=kgt[0] - 10.0, fy_max=2000.0, cx_max=1280.0, cy_max=720.0)
     rb = optim.optimize_intrinsics_semidlt(views, d["kappa0"], seeds, opt, bounds=b)
     assert rb.camera[0] == kgt[0] - 10.0
+
+
+# ---- batched estimate_planar_pose on the GPU -------------------------------------------------------------
+def test_planar_seed_batch_on_gpu(gpu_lib):
+    from tests.planar_seed import estimate_planar_pose
+    from tests.test_host_logic import _seed_views
+
+    for noise in (0.0, 0.3):
+        cam, views, poses = _seed_views(n_views=40, noise=noise)
+        views.append(views[0][:3])  # < 4 points -> identity
+        got = optim.estimate_planar_pose_batch(views, cam[:5])
+        assert np.array_equal(got[-1], np.eye(4))
+        for view, T, Tgt in zip(views[:-1], got, poses):
+            Tr = estimate_planar_pose(view, cam[:5])
+            assert np.abs(T - Tr).max() <= (1e-9 if len(view) > 4 else 1e-7)
+            if noise == 0.0:
+                assert np.abs(T - Tgt).max() <= 1e-8
+    # the reference's calling pattern: optimize_intrinsics_semidlt seeds every view itself (intrinsicssemidlt.cpp:37-40)
+    d, kgt, agt = helpers.semidlt_scene(8, noise=0.0, nr=2, seed=21)
+    vs = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][:-1], d["off"][1:])]
+    r = optim.optimize_intrinsics_semidlt(vs, d["kappa0"], None, optim.IntrinsicsOptimOptions(core=optim.OptimOptions(epsilon=1e-12)))
+    assert r.core.success and np.abs(r.camera[:4] - kgt[:4]).max() <= 1e-6 and np.abs(r.distortion - agt).max() <= 1e-7
+    with pytest.raises(ValueError, match="out of range"):
+        optim.optimize_intrinsics_semidlt(vs, d["kappa0"], None, fixed_distortion_indices=[7])

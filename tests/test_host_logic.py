@@ -475,3 +475,51 @@ def test_semidlt_lm_matches_oracle(oracle, hostmath, case):
         assert kb[1] == hi[1] == ka[1]
     if case.get("fixed"):
         assert db[1] == 0.0
+
+
+def test_semidlt_distortion_fit_reference_kats(oracle, hostmath):
+    """distortion_test.cpp:61-82 (ExactFit, 1e-10), :128-150 (RespectsFixedCoefficientConstraints: fixed entries returned bit-exact,
+    free ones to 1e-10) and :152-167 (out-of-range fixed index -> std::invalid_argument), exercised through solve_full of the
+    semi-DLT path (intrinsicssemidlt.cpp:74-90) at the exact camera and poses."""
+    d, kgt, agt = helpers.semidlt_scene(5, noise=0.0, nr=2)
+    d = dict(d, kappa0=kgt.copy(), poses0=np.ascontiguousarray(d["poses_gt"].copy()))
+    o = options(max_iterations=0)
+    for fn in (oracle.orc_semidlt_solve, hostmath.hm_semidlt_solve):
+        st, k, p, s, dist, ve, _ = helpers.semidlt_solve(fn, d, 2, o, want_cov=False)
+        assert st == 0 and np.abs(dist - agt).max() <= 1e-10 and np.array_equal(k, kgt)
+        st, k, p, s, dist, ve, _ = helpers.semidlt_solve(fn, d, 2, o, fixed=[(0, agt[0]), (3, agt[3])], want_cov=False)
+        assert st == 0 and dist[0] == agt[0] and dist[3] == agt[3] and np.abs(dist[1:3] - agt[1:3]).max() <= 1e-10
+        st = helpers.semidlt_solve(fn, d, 2, o, fixed=[(7, 0.0)], want_cov=False)[0]
+        assert st != 0
+    assert b"out of range" in oracle.orc_last_error() and b"out of range" in hostmath.hm_semidlt_last_error()
+
+
+# ---- per-view pose seed (estimate_planar_pose): the product's inverse-iteration / polar-factor route vs the SVD restatement ----
+def _seed_views(seed=4, n_views=12, noise=0.0):
+    rng = np.random.default_rng(seed)
+    cam = synth.camera_gt(0, distortion=False)
+    views, poses = [], synth.random_view_poses(n_views, rng, dist=1.2, max_tilt_deg=35.0, jitter=0.15)
+    for i, T in enumerate(poses):
+        rows, cols = [(2, 2), (3, 4), (8, 11), (30, 30)][i % 4]
+        views.append(synth.render_view(cam, T, synth.make_target_grid(rows, cols, 0.05), noise, rng, cull=False))
+    return cam, views, poses
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.3])
+def test_planar_seed_matches_svd_restatement(hostmath, noise):
+    from tests.planar_seed import estimate_planar_pose
+    from calibration_amd.geometry import pose_to_matrix
+
+    cam, views, poses = _seed_views(noise=noise)
+    for view, Tgt in zip(views, poses):
+        X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+        p = np.zeros(7)
+        hostmath.hm_planar_seed(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(np.ascontiguousarray(cam[:5])), dptr(p))
+        T = pose_to_matrix(p)
+        Tr = estimate_planar_pose(view, cam[:5])
+        assert np.abs(T - Tr).max() <= (1e-9 if len(view) > 4 else 1e-7), (len(view), np.abs(T - Tr).max())
+        if noise == 0.0:  # posefromhomography_test.cpp bar for exact data: the true pose comes back
+            assert np.abs(T - Tgt).max() <= 1e-8
+    p = np.ones(7)
+    hostmath.hm_planar_seed(3, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(np.ascontiguousarray(cam[:5])), dptr(p))
+    assert np.array_equal(p, [1, 0, 0, 0, 0, 0, 0])  # < 4 points: identity (planarpose_linear.cpp:55-57)
