@@ -490,10 +490,17 @@ int64_t covariance_dim(const Engine& e) {
     return n;
 }
 
-void compute_covariance(Engine& e, const cba_options& o, double* cov) {
+int64_t shared_covariance_dim(const Engine& e) {
+    if (e.chain == CBA_CHAIN_BUNDLE) return covariance_dim(e);
+    int64_t n = static_cast<int64_t>(e.n_cams) * e.PI;
+    if (e.chain != CBA_CHAIN_INTRINSIC) n += 7LL * e.n_cams;
+    return n;
+}
+
+void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only) {
     HipBackend be(e, *lm_state(e));
     LMDriver drv = make_driver(e, be);
-    drv.covariance(o, cov);
+    drv.covariance(o, cov, shared_only);
 }
 
 }  // namespace cba

@@ -523,6 +523,17 @@ cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double*
     });
 }
 
+int64_t cba_reproj_covariance_shared_dim(const cba_reproj* h) { return h ? shared_covariance_dim(*reinterpret_cast<const Engine*>(h)) : 0; }
+
+cba_status cba_reproj_covariance_shared(cba_reproj* h, const cba_options* opts, double* cov) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (!opts || !cov) throw std::invalid_argument("null argument");
+        CBA_HIP(hipSetDevice(e.device));
+        compute_covariance(e, *opts, cov, true);
+    });
+}
+
 cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank) {
     return guarded([&] {
         Engine& e = *as_engine(h);

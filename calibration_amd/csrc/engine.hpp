@@ -168,8 +168,9 @@ void launch_cost(Engine& e, double huber_delta);        // scalar_out[0] = 1/2 s
 void init_lm_state(Engine& e, const cba_reproj_problem& d);
 void destroy_lm_state(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
-void compute_covariance(Engine& e, const cba_options& o, double* cov);
+void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
 int64_t covariance_dim(const Engine& e);
+int64_t shared_covariance_dim(const Engine& e);
 void engine_allreduce(Engine& e, double* host_buf, int64_t count);
 void rccl_unique_id(uint8_t* id);
 void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank);

@@ -205,10 +205,21 @@ class LMDriver {
         return n;
     }
 
-    void covariance(const cba_options& o, double* cov) {
+    // Shared blocks only — [intr[c]..., camera quats, camera trans] (everything but the per-view poses): the marginal
+    // covariance of the parameters a calibration is run for, O(#views) work and O(shared^2) output where the reference's
+    // all-block-pairs matrix is O(#views^2) (6.3 GB at C3).  SURVEY.md §8(f) rank 2.
+    int64_t shared_covariance_dim() const {
+        if (s_.chain == CBA_CHAIN_BUNDLE) return covariance_dim();
+        int64_t n = static_cast<int64_t>(s_.n_cams) * s_.PI;
+        if (s_.chain != CBA_CHAIN_INTRINSIC) n += 7LL * s_.n_cams;
+        return n;
+    }
+
+    void covariance(const cba_options& o, double* cov, bool shared_only = false) {
         setup(o);
         const int n = s_.nsh, PL = s_.PL, NH = s_.NH, NACC = s_.NACC;
-        if (covariance_dim() > 20000) throw std::runtime_error("covariance: dense ambient matrix too large (use compute_covariance=false)");
+        if (!shared_only && covariance_dim() > 20000)
+            throw std::runtime_error("covariance: dense ambient matrix too large (use cba_reproj_covariance_shared or compute_covariance=false)");
         be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
         std::vector<double> cam_acc, acc, w;
         double cost2[2];
@@ -294,12 +305,12 @@ class LMDriver {
             chol_inverse(Lc, na, Scc);
         }
         // tangent covariance: [shared active (na) | free views (6 each)]
-        const int nt = na + 6 * nv;
+        const int nt = shared_only ? na : na + 6 * nv;
         std::vector<double> T(static_cast<size_t>(nt) * nt, 0.0);
         for (int a = 0; a < na; ++a)
             for (int b = 0; b < na; ++b) T[static_cast<size_t>(a) * nt + b] = Scc[static_cast<size_t>(a) * na + b];
-        std::vector<double> WS(static_cast<size_t>(nv) * 6 * std::max(na, 1), 0.0);  // W_v Scc
-        for (int fv = 0; fv < nv; ++fv)
+        std::vector<double> WS(shared_only ? 0 : static_cast<size_t>(nv) * 6 * std::max(na, 1), 0.0);  // W_v Scc
+        for (int fv = 0; fv < (shared_only ? 0 : nv); ++fv)
             for (int i = 0; i < 6; ++i)
                 for (int b = 0; b < na; ++b) {
                     double sum = 0;
@@ -309,7 +320,7 @@ class LMDriver {
                     T[static_cast<size_t>(na + 6 * fv + i) * nt + b] = -sum;
                     T[static_cast<size_t>(b) * nt + na + 6 * fv + i] = -sum;
                 }
-        for (int fv = 0; fv < nv; ++fv)
+        for (int fv = 0; fv < (shared_only ? 0 : nv); ++fv)
             for (int fw = 0; fw < nv; ++fw)
                 for (int i = 0; i < 6; ++i)
                     for (int j = 0; j < 6; ++j) {
@@ -346,7 +357,9 @@ class LMDriver {
             for (int c = 0; c < s_.n_cams; ++c) { sh3(campose_base(c), t3); push_quat(&cam_[7 * static_cast<size_t>(c)], t3); }
             for (int c = 0; c < s_.n_cams; ++c) push_euclid(campose_base(c) + 3, 3);
         }
-        if (s_.chain != CBA_CHAIN_BUNDLE) {
+        if (s_.chain != CBA_CHAIN_BUNDLE && shared_only) {
+            // per-view blocks omitted
+        } else if (s_.chain != CBA_CHAIN_BUNDLE) {
             std::vector<int> fidx(s_.n_views, -1);
             for (int fv = 0; fv < nv; ++fv) fidx[free_views[fv]] = fv;
             for (int v = 0; v < s_.n_views; ++v) {

@@ -384,6 +384,16 @@ class ReprojHandle:
         capi.check(self.lib, st)
         return cov
 
+    def covariance_shared(self, opts: CbaOptions) -> Optional[np.ndarray]:
+        """Marginal covariance of the shared blocks only (cba_reproj_covariance_shared): O(#views) work."""
+        n = int(self.lib.cba_reproj_covariance_shared_dim(self.h))
+        cov = np.zeros((n, n))
+        st = self.lib.cba_reproj_covariance_shared(self.h, C.byref(opts), dptr(cov))
+        if st == capi.CBA_ERR_RUNTIME:
+            return None
+        capi.check(self.lib, st)
+        return cov
+
     def set_allreduce(self, fn, n_ranks: int, rank: int):
         """fn(np.ndarray) sums the array in place across ranks (host buffers)."""
 

@@ -207,6 +207,13 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
 int64_t cba_reproj_covariance_dim(const cba_reproj* h);
 cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double* cov /*[dim*dim]*/);
 
+/* The same matrix restricted to the SHARED blocks — [intr[c]..., camera quats, camera trans] (for BUNDLE: every block) — i.e.
+ * the marginal covariance of everything but the per-view poses, from the Schur-reduced system: O(#views) work and a
+ * (shared dim)^2 result where the all-block-pairs matrix of ceresutils.h:80-84 is O(#views^2) (393 MB at 1000 views, 6.3 GB
+ * at 4000).  Equal to the corresponding rows/columns of cba_reproj_covariance. */
+int64_t cba_reproj_covariance_shared_dim(const cba_reproj* h);
+cba_status cba_reproj_covariance_shared(cba_reproj* h, const cba_options* opts, double* cov /*[dim*dim]*/);
+
 /* ---- multi-GPU: views sharded across ranks, one sum-all-reduce per LM linear solve ---------- */
 /* Host-buffer callback (any transport: gloo, MPI, ...): in-place sum of buf[count] over ranks. */
 typedef int32_t (*cba_allreduce_fn)(double* buf, int64_t count, void* user);

@@ -257,4 +257,22 @@ int hm_reproj_covariance(const cba_reproj_problem* d, const cba_options* o, doub
     });
 }
 
+int64_t hm_reproj_covariance_shared_dim(const cba_reproj_problem* d) {
+    Session ss;
+    try { load(*d, ss); } catch (...) { return -1; }
+    CpuBackend be(ss.s, *d, ss.view);
+    LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+    return drv.shared_covariance_dim();
+}
+
+int hm_reproj_covariance_shared(const cba_reproj_problem* d, const cba_options* o, double* cov) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+        drv.covariance(*o, cov, true);
+    });
+}
+
 }  // extern "C"

@@ -64,6 +64,9 @@ def load_hostmath():
     h.hm_reproj_covariance_dim.argtypes = [PP]
     h.hm_reproj_covariance_dim.restype = C.c_int64
     h.hm_reproj_covariance.argtypes = [PP, PO, c_double_p]
+    h.hm_reproj_covariance_shared_dim.argtypes = [PP]
+    h.hm_reproj_covariance_shared_dim.restype = C.c_int64
+    h.hm_reproj_covariance_shared.argtypes = [PP, PO, c_double_p]
     h.hm_planar_vp_eval.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p,
                                     c_double_p, c_double_p, c_double_p, c_double_p]
     h.hm_planar_pose_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, PO, PS,

@@ -228,6 +228,13 @@ def test_covariance_assembly_matches_oracle(oracle, hostmath, kind):
     assert np.array_equal(d0 == 0, np.diag(cov1) == 0)
     nz = d0 > 0
     assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-5
+    # the shared-block marginal is exactly the leading rows/columns of the full matrix
+    ns = int(hostmath.hm_reproj_covariance_shared_dim(C.byref(d)))
+    per_cam = b.flat.intr.shape[-1] + (0 if kind == "intr" else 7)
+    assert ns == (n if kind.startswith("bundle") else per_cam * b.flat.n_cams)
+    cov2 = np.zeros((ns, ns))
+    assert hostmath.hm_reproj_covariance_shared(C.byref(d), C.byref(o), dptr(cov2)) == 0, hostmath.hm_last_error()
+    assert np.array_equal(cov2, cov1[:ns, :ns])
 
 
 def test_shard_views_partitions_the_problem():
