@@ -227,7 +227,8 @@ struct HipLMState {
     DevBuf<int32_t> link_blk;
     DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
     DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
-    std::vector<double> schur_host;
+    PinnedBuf<double> pin;      // host staging of every per-step D2H result (one stream sync per stage)
+    PinnedBuf<int32_t> pin_i;
 };
 
 struct HipBackend final : Backend {
@@ -261,9 +262,13 @@ struct HipBackend final : Backend {
         launch_cost(e, huber);
         CBA_HIP(hipGetLastError());
         cam_acc.resize(static_cast<size_t>(s.n_cams) * s.NACC);
-        e.cam_acc.download(cam_acc.data(), cam_acc.size(), e.stream);
-        e.scalar_out.download(cost2, 2, e.stream);
+        st.pin.reserve(cam_acc.size() + 2);
+        e.cam_acc.download(st.pin.p, cam_acc.size(), e.stream);
+        e.scalar_out.download(st.pin.p + cam_acc.size(), 2, e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
+        std::memcpy(cam_acc.data(), st.pin.p, sizeof(double) * cam_acc.size());
+        cost2[0] = st.pin.p[cam_acc.size()];
+        cost2[1] = st.pin.p[cam_acc.size() + 1];
     }
     void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
                int* nfail) override {
@@ -291,12 +296,14 @@ struct HipBackend final : Backend {
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
                            st.schur_pack.p + sw + n);
         CBA_HIP(hipGetLastError());
-        std::vector<double>& tiles = st.schur_host;
-        tiles.resize(static_cast<size_t>(sw) + n + 1);
-        st.schur_pack.download(tiles.data(), tiles.size(), e.stream);
-        int32_t nf = 0;
-        st.nfail.download(&nf, 1, e.stream);
+        const size_t n_pack = static_cast<size_t>(sw) + n + 1;
+        st.pin.reserve(n_pack);
+        st.pin_i.reserve(1);
+        st.schur_pack.download(st.pin.p, n_pack, e.stream);
+        st.nfail.download(st.pin_i.p, 1, e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
+        const double* tiles = st.pin.p;
+        const int32_t nf = st.pin_i.p[0];
         for (int i = 0; i < n; ++i) g[i] = tiles[static_cast<size_t>(sw) + i];
         *gmax_priv = tiles[static_cast<size_t>(sw) + n];
         *nfail = nf;
@@ -332,11 +339,12 @@ struct HipBackend final : Backend {
         launch_block_consts(e, 1);
         launch_resid_trial(e, huber);
         CBA_HIP(hipGetLastError());
-        double h[24] = {0};
-        st.small_out.download(h, 24, e.stream);
-        double c2[2];
-        e.scalar_out.download(c2, 2, e.stream);
+        st.pin.reserve(26);
+        st.small_out.download(st.pin.p, 24, e.stream);
+        e.scalar_out.download(st.pin.p + 24, 2, e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
+        const double* h = st.pin.p;
+        const double* c2 = st.pin.p + 24;
         out->step2 = s.n_views > 0 ? h[8] : 0.0;
         out->xnorm2 = s.n_views > 0 ? h[9] : 0.0;
         out->gd = s.n_views > 0 ? h[10] : 0.0;

@@ -72,6 +72,25 @@ struct DevBuf {
     void zero(hipStream_t s) { CBA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
 
+// Page-locked host staging for the small device-to-host results of an LM step: a copy into pageable memory blocks the
+// host once per call, a copy into pinned memory is queued on the stream and only the single hipStreamSynchronize waits.
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void reserve(size_t count) {
+        if (count <= n) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
 struct Tile {          // 32 bytes, read with scalar loads (wave-uniform)
     int32_t blk;       // residual block
     int32_t count;     // observations in this tile (Mode A: padded, even; Mode B/R: valid count)
