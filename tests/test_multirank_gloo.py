@@ -107,3 +107,69 @@ def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw):
         views = np.concatenate([r["view"].reshape(-1, 7) for r in res])
         assert helpers.rel_diff(ref.view_pose.reshape(-1, 7), views) <= 1e-9
         assert int(res[0]["first"]) == 0 and int(res[1]["first"]) == res[0]["view"].reshape(-1, 7).shape[0]
+
+
+# ---- GPU tier: the same 2-rank protocol with the REAL engine (HIP kernels per rank, both ranks on GPU 0), gloo transport --------
+def _gpu_worker(rank, world, port, kind, okw, outdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calibration_amd import optim, synth
+    from tests import helpers
+
+    flat = synth.shard_views(_scene(kind).flat, rank, world)
+    calls = []
+
+    def allreduce(arr):
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t)
+        calls.append(arr.size)
+
+    o = helpers.options(epsilon=1e-12, **okw)
+    with optim.ReprojHandle(flat, device=0) as h:
+        h.set_allreduce(allreduce, world, rank)
+        s = h.solve(o)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), intr=flat.intr, cam=flat.cam_pose if flat.cam_pose is not None else np.zeros(0),
+             view=flat.view_pose if flat.view_pose is not None else np.zeros(0), iters=s.iterations, cost=s.final_cost,
+             term=s.termination, ncalls=len(calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,okw", [("intr", {}), ("ext", {})])
+def test_two_ranks_on_the_gpu_engine_match_one_rank(tmp_path, kind, okw):
+    """Two processes, each with its own engine handle on GPU 0 and half of the views; the packed sum-all-reduces go through
+    the host-callback transport over gloo.  (The RCCL transport needs one GPU per rank: exercised by the driver's N > 1 runs.)"""
+    import torch.multiprocessing as mp
+
+    from calibration_amd import optim
+    from tests import helpers
+
+    world = 2
+    ctx = mp.start_processes(_gpu_worker, args=(world, _free_port(), kind, okw, str(tmp_path)), nprocs=world, join=False,
+                             start_method="spawn")
+    import time
+
+    deadline = time.time() + 180
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("2-rank GPU solve did not finish in 180 s")
+    res = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    ref = _scene(kind).flat
+    o = helpers.options(epsilon=1e-12, **okw)
+    with optim.ReprojHandle(ref, device=0) as h:
+        s = h.solve(o)
+    for r in res:
+        assert int(r["term"]) == s.termination and abs(int(r["iters"]) - s.iterations) <= 1 and int(r["ncalls"]) >= 2
+        assert abs(float(r["cost"]) - s.final_cost) <= 1e-9 * max(1.0, s.final_cost)
+        assert helpers.rel_diff(ref.intr, r["intr"]) <= 1e-9
+        if ref.cam_pose is not None:
+            assert helpers.rel_diff(ref.cam_pose, r["cam"]) <= 1e-9
+    assert np.array_equal(res[0]["intr"], res[1]["intr"]) and np.array_equal(res[0]["cam"], res[1]["cam"])
+    views = np.concatenate([r["view"].reshape(-1, 7) for r in res])
+    assert helpers.rel_diff(ref.view_pose.reshape(-1, 7), views) <= 1e-9
