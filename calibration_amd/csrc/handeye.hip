@@ -5,7 +5,7 @@
 // from the two poses' rotations/translations (24 doubles each, L2-resident), applies the reference's
 // pair filter, evaluates residual + analytic tangent Jacobian, applies the per-pair Huber weight and
 // accumulates [H | g | cost | count] — wave-shuffle + LDS reduction per workgroup, then a fixed-order
-// sum over workgroups (no atomics; bitwise reproducible).  Compute-bound: ~1.2 kFLOP per pair.
+// two-level sum over workgroups (no atomics; bitwise reproducible).  Compute-bound: ~1.2 kFLOP per pair.
 #include "engine.hpp"
 #include "handeye_core.hpp"
 #include "wave_reduce.hpp"
@@ -43,19 +43,33 @@ __global__ __launch_bounds__(256) void k_axxb(int n, const double* __restrict__ 
             (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-__global__ void k_axxb_sum(int64_t n_rows, const double* __restrict__ rows, double* __restrict__ out) {
-    const int e = threadIdx.x;
-    if (e >= AXXB_NACC) return;
+// out[b][e] = sum of rows [b * chunk, (b + 1) * chunk) of a row-major [n_rows][AXXB_NACC] table, in a FIXED order: thread
+// (column e, group r) adds rows r, r + 8, ... of the chunk, the 8 group sums are combined in group order through LDS.
+// Applied twice (chunks of 64 rows, then the <= few hundred chunk sums) it replaces one wave walking all ~16 000 workgroup
+// partials of a 2000-pose problem serially (3.8 ms per evaluation, 17x the pair kernel itself).
+__global__ __launch_bounds__(256) void k_axxb_chunk_sum(int64_t n_rows, int64_t chunk, const double* __restrict__ rows,
+                                                        double* __restrict__ out) {
+    __shared__ double sh[8][32];
+    const int e = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * chunk, t1 = t0 + chunk < n_rows ? t0 + chunk : n_rows;
     double s = 0.0;
-    for (int64_t t = 0; t < n_rows; ++t) s += rows[t * AXXB_NACC + e];
-    out[e] = s;
+    if (e < AXXB_NACC)
+        for (int64_t t = t0 + r; t < t1; t += 8) s += rows[t * AXXB_NACC + e];
+    sh[r][e] = s;
+    __syncthreads();
+    if (r == 0 && e < AXXB_NACC) {
+        double tot = 0.0;
+        for (int k = 0; k < 8; ++k) tot += sh[k][e];
+        out[static_cast<int64_t>(blockIdx.x) * AXXB_NACC + e] = tot;
+    }
 }
 
 namespace {
 struct HipAxxb final : AxxbEval {
     int n;
     hipStream_t stream = nullptr;
-    DevBuf<double> poses, X, partial, out;
+    DevBuf<double> poses, X, partial, partial2, out;
+    int64_t n_rows = 0, n_chunks = 0;
     dim3 grid;
     HipAxxb(int n_poses, const double* bTg, const double* cTt) : n(n_poses) {
         CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -72,7 +86,10 @@ struct HipAxxb final : AxxbEval {
         grid = dim3((n + 255) / 256, std::max(1, n - 1));
         poses.alloc(h.size()); poses.upload(h.data(), h.size(), stream);
         X.alloc(12); out.alloc(AXXB_NACC);
-        partial.alloc(static_cast<size_t>(grid.x) * grid.y * AXXB_NACC);
+        n_rows = static_cast<int64_t>(grid.x) * grid.y;
+        n_chunks = (n_rows + 63) / 64;
+        partial.alloc(static_cast<size_t>(n_rows) * AXXB_NACC);
+        partial2.alloc(static_cast<size_t>(n_chunks) * AXXB_NACC);
         CBA_HIP(hipStreamSynchronize(stream));
     }
     ~HipAxxb() override { if (stream) (void)hipStreamDestroy(stream); }
@@ -84,7 +101,8 @@ struct HipAxxb final : AxxbEval {
         constexpr double kMinAngleDeg = 0.5;  // handeye.cpp:64
         hipLaunchKernelGGL(k_axxb, grid, dim3(256), 0, stream, n, poses.p, X.p, kMinAngleDeg * 3.14159265358979323846 / 180.0, 1e-3,
                            huber_delta, partial.p);
-        hipLaunchKernelGGL(k_axxb_sum, dim3(1), dim3(64), 0, stream, static_cast<int64_t>(grid.x) * grid.y, partial.p, out.p);
+        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, stream, n_rows, int64_t{64}, partial.p, partial2.p);
+        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, stream, n_chunks, n_chunks, partial2.p, out.p);
         CBA_HIP(hipGetLastError());
         out.download(acc, AXXB_NACC, stream);
         CBA_HIP(hipStreamSynchronize(stream));
