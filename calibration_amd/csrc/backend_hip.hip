@@ -227,7 +227,7 @@ struct HipLMState {
     DevBuf<int32_t> link_blk;
     DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
     DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
-    PinnedBuf<double> pin;      // host staging of every per-step D2H result (one stream sync per stage)
+    PinnedBuf<double> pin, pin_ne;  // host staging of every per-step D2H result (one stream sync per stage)
     PinnedBuf<int32_t> pin_i;
 };
 
@@ -247,10 +247,30 @@ struct HipBackend final : Backend {
         // pageable host memory: the copy has been staged when the call returns
     }
     void normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) override {
+        if (!queue_normal_eq(huber, cam_acc, cost2)) return;
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        collect_normal_eq(cam_acc, cost2);
+    }
+    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
+               int* nfail) override {
+        if (!queue_schur(radius, init_scale, constrained, S, g, gmax_priv, nfail)) return;
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        collect_schur(S, g, gmax_priv, nfail);
+    }
+    // a new linearisation: every kernel of both stages and both result copies are queued, ONE stream synchronisation
+    void normal_eq_schur(double huber, std::vector<double>& cam_acc, double cost2[2], double radius, bool init_scale, bool constrained,
+                         std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) override {
+        const bool q1 = queue_normal_eq(huber, cam_acc, cost2);
+        const bool q2 = queue_schur(radius, init_scale, constrained, S, g, gmax_priv, nfail);
+        if (q1 || q2) CBA_HIP(hipStreamSynchronize(e.stream));
+        if (q1) collect_normal_eq(cam_acc, cost2);
+        if (q2) collect_schur(S, g, gmax_priv, nfail);
+    }
+    bool queue_normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) {
         const Structure& s = st.s;
         cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
         cost2[0] = cost2[1] = 0.0;
-        if (s.n_blocks == 0) return;
+        if (s.n_blocks == 0) return false;
         launch_block_consts(e, 0);
         launch_normal_eq(e);
         hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
@@ -262,23 +282,25 @@ struct HipBackend final : Backend {
         launch_cost(e, huber);
         CBA_HIP(hipGetLastError());
         cam_acc.resize(static_cast<size_t>(s.n_cams) * s.NACC);
-        st.pin.reserve(cam_acc.size() + 2);
-        e.cam_acc.download(st.pin.p, cam_acc.size(), e.stream);
-        e.scalar_out.download(st.pin.p + cam_acc.size(), 2, e.stream);
-        CBA_HIP(hipStreamSynchronize(e.stream));
-        std::memcpy(cam_acc.data(), st.pin.p, sizeof(double) * cam_acc.size());
-        cost2[0] = st.pin.p[cam_acc.size()];
-        cost2[1] = st.pin.p[cam_acc.size() + 1];
+        st.pin_ne.reserve(cam_acc.size() + 2);
+        e.cam_acc.download(st.pin_ne.p, cam_acc.size(), e.stream);
+        e.scalar_out.download(st.pin_ne.p + cam_acc.size(), 2, e.stream);
+        return true;
     }
-    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
-               int* nfail) override {
+    void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
+        std::memcpy(cam_acc.data(), st.pin_ne.p, sizeof(double) * cam_acc.size());
+        cost2[0] = st.pin_ne.p[cam_acc.size()];
+        cost2[1] = st.pin_ne.p[cam_acc.size() + 1];
+    }
+    bool queue_schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
+                     int* nfail) {
         const Structure& s = st.s;
         const int n = s.nsh;
         S.assign(static_cast<size_t>(n) * n, 0.0);
         g.assign(n, 0.0);
         *gmax_priv = 0.0;
         *nfail = 0;
-        if (s.n_views == 0) return;
+        if (s.n_views == 0) return false;
         CBA_HIP(hipMemsetAsync(st.nfail.p, 0, sizeof(int32_t), e.stream));
         hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                            st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, radius, init_scale ? 1 : 0, constrained ? 1 : 0,
@@ -301,7 +323,12 @@ struct HipBackend final : Backend {
         st.pin_i.reserve(1);
         st.schur_pack.download(st.pin.p, n_pack, e.stream);
         st.nfail.download(st.pin_i.p, 1, e.stream);
-        CBA_HIP(hipStreamSynchronize(e.stream));
+        return true;
+    }
+    void collect_schur(std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) {
+        const Structure& s = st.s;
+        const int n = s.nsh;
+        const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         const double* tiles = st.pin.p;
         const int32_t nf = st.pin_i.p[0];
         for (int i = 0; i < n; ++i) g[i] = tiles[static_cast<size_t>(sw) + i];

@@ -48,6 +48,12 @@ struct Backend {
     // per-view elimination with the given radius; S_schur [nsh*nsh], g_schur [nsh] (this rank's views)
     virtual void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g,
                        double* gmax_priv, int* nfail) = 0;
+    // both of the above for a new linearisation; a device backend overrides it to queue everything and wait once
+    virtual void normal_eq_schur(double huber, std::vector<double>& cam_acc, double cost2[2], double radius, bool init_scale,
+                                 bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) {
+        normal_eq(huber, cam_acc, cost2);
+        schur(radius, init_scale, constrained, S, g, gmax_priv, nfail);
+    }
     // back-substitute delta_sh, write private trial poses (copy 1), model terms, trial cost
     virtual void trial(const double* delta_sh, double huber, TrialStats* st) = 0;
     virtual void accept() = 0;  // private copy 1 -> copy 0
@@ -426,8 +432,7 @@ class LMDriver {
         std::vector<double> cam_acc, S, g;
         double cost2[2] = {0, 0}, gmax_priv = 0;
         int nfail = 0;
-        be_.normal_eq(huber, cam_acc, cost2);
-        be_.schur(radius, init_scale, constrained_, S, g, &gmax_priv, &nfail);
+        be_.normal_eq_schur(huber, cam_acc, cost2, radius, init_scale, constrained_, S, g, &gmax_priv, &nfail);
         const size_t nca = cam_acc.size();
         std::vector<double> buf(nca + 2 + static_cast<size_t>(n) * n + n + n_ranks_, 0.0);
         std::memcpy(buf.data(), cam_acc.data(), sizeof(double) * nca);
