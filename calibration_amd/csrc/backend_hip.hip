@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* 
 
 __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
                              const double* __restrict__ blk_acc, const double* __restrict__ blk_w,
-                             const int32_t* __restrict__ fixed, double radius, int init_scale, int constrained,
+                             const int32_t* __restrict__ fixed, const double* __restrict__ lmp /*[radius, init_scale]*/, int constrained,
                              const double* __restrict__ view, double* __restrict__ scale2, double* __restrict__ L,
                              double* __restrict__ y, double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
                              double* __restrict__ gmax, int* __restrict__ nfail) {
@@ -124,7 +124,9 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
     double gm = 0.0;
-    const bool ok = schur_view_body(d, nb, link_blk + link_off[v], blk_acc, blk_w, fixed[v] != 0, radius, init_scale != 0,
+    const double radius = lmp[0];
+    const bool init_scale = lmp[1] != 0.0;
+    const bool ok = schur_view_body(d, nb, link_blk + link_off[v], blk_acc, blk_w, fixed[v] != 0, radius, init_scale,
                                     constrained != 0, view + 7 * static_cast<int64_t>(v), scale2 + 6 * static_cast<int64_t>(v),
                                     L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
                                     gp + 6 * static_cast<int64_t>(v), blk_Z, &gm);
@@ -227,8 +229,27 @@ struct HipLMState {
     DevBuf<int32_t> link_blk;
     DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
     DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
-    PinnedBuf<double> pin, pin_ne;  // host staging of every per-step D2H result (one stream sync per stage)
+    PinnedBuf<double> pin, pin_ne, pin_tr;  // host staging of every per-step D2H result (one stream sync per stage)
     PinnedBuf<int32_t> pin_i;
+    // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
+    // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
+    // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches
+    // travels through memory the graph's own copy nodes read at execution time: [radius, init_scale] and the shared step
+    // in pinned host buffers.  Values baked into kernel arguments (huber, constrained, fp32 mode) key the graph.
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        double huber = 0.0;
+        int constrained = -1, scalar = -1;
+        int uses = 0;  // plain launches of this stage with the current key so far
+        ~GraphSlot() { if (exec) (void)hipGraphExecDestroy(exec); }
+    };
+    GraphSlot g_new, g_schur, g_trial;
+    bool graphs_ok = true;
+    int graph_after = 24; // capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
+                          // than a handful of iterations (or a handle that is solved again), so a stage runs as plain
+                          // launches until it has been used this many times with the same key (CBA_LM_GRAPH=<n>, 0 = never)
+    DevBuf<double> lmp;          // device [radius, init_scale]
+    PinnedBuf<double> pin_lmp, pin_delta;
 };
 
 struct HipBackend final : Backend {
@@ -246,31 +267,58 @@ struct HipBackend final : Backend {
         if (e.chain == CBA_CHAIN_BUNDLE) e.target[which].upload(target, 7, e.stream);
         // pageable host memory: the copy has been staged when the call returns
     }
-    void normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) override {
-        if (!queue_normal_eq(huber, cam_acc, cost2)) return;
-        CBA_HIP(hipStreamSynchronize(e.stream));
-        collect_normal_eq(cam_acc, cost2);
+    // ---- stage plumbing: host preparation (every call) / device enqueue (captured once) / result collection ----------
+    template <class F>
+    void run_stage(HipLMState::GraphSlot& slot, double huber, bool constrained, F&& enqueue) {
+        if (!st.graphs_ok) { enqueue(); return; }
+        if (slot.huber != huber || slot.constrained != static_cast<int>(constrained) || slot.scalar != e.scalar) {
+            if (slot.exec) (void)hipGraphExecDestroy(slot.exec);
+            slot.exec = nullptr;
+            slot.uses = 0;
+            slot.huber = huber; slot.constrained = static_cast<int>(constrained); slot.scalar = e.scalar;
+        }
+        if (!slot.exec && slot.uses < st.graph_after) {
+            ++slot.uses;
+            enqueue();
+            return;
+        }
+        if (!slot.exec) {
+            if (hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();
+                st.graphs_ok = false;
+                enqueue();
+                return;
+            }
+            hipGraph_t graph = nullptr;
+            try {
+                enqueue();
+            } catch (...) {
+                (void)hipStreamEndCapture(e.stream, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            const hipError_t ec = hipStreamEndCapture(e.stream, &graph);
+            const hipError_t ei = (ec == hipSuccess && graph) ? hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0) : hipErrorUnknown;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) {  // no graph support for this sequence: plain launches from now on
+                (void)hipGetLastError();
+                slot.exec = nullptr;
+                st.graphs_ok = false;
+                enqueue();
+                return;
+            }
+        }
+        CBA_HIP(hipGraphLaunch(slot.exec, e.stream));
     }
-    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
-               int* nfail) override {
-        if (!queue_schur(radius, init_scale, constrained, S, g, gmax_priv, nfail)) return;
-        CBA_HIP(hipStreamSynchronize(e.stream));
-        collect_schur(S, g, gmax_priv, nfail);
-    }
-    // a new linearisation: every kernel of both stages and both result copies are queued, ONE stream synchronisation
-    void normal_eq_schur(double huber, std::vector<double>& cam_acc, double cost2[2], double radius, bool init_scale, bool constrained,
-                         std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) override {
-        const bool q1 = queue_normal_eq(huber, cam_acc, cost2);
-        const bool q2 = queue_schur(radius, init_scale, constrained, S, g, gmax_priv, nfail);
-        if (q1 || q2) CBA_HIP(hipStreamSynchronize(e.stream));
-        if (q1) collect_normal_eq(cam_acc, cost2);
-        if (q2) collect_schur(S, g, gmax_priv, nfail);
-    }
-    bool queue_normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) {
+
+    bool prep_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
         const Structure& s = st.s;
         cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
         cost2[0] = cost2[1] = 0.0;
-        if (s.n_blocks == 0) return false;
+        return s.n_blocks != 0;
+    }
+    void enqueue_normal_eq(double huber) {
+        const Structure& s = st.s;
         launch_block_consts(e, 0);
         launch_normal_eq(e);
         hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
@@ -281,19 +329,17 @@ struct HipBackend final : Backend {
                            s.NACC, st.cam_seg.p, st.cam_partial.p, e.cam_acc.p);
         launch_cost(e, huber);
         CBA_HIP(hipGetLastError());
-        cam_acc.resize(static_cast<size_t>(s.n_cams) * s.NACC);
-        st.pin_ne.reserve(cam_acc.size() + 2);
-        e.cam_acc.download(st.pin_ne.p, cam_acc.size(), e.stream);
-        e.scalar_out.download(st.pin_ne.p + cam_acc.size(), 2, e.stream);
-        return true;
+        const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
+        e.cam_acc.download(st.pin_ne.p, nca, e.stream);
+        e.scalar_out.download(st.pin_ne.p + nca, 2, e.stream);
     }
     void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
         std::memcpy(cam_acc.data(), st.pin_ne.p, sizeof(double) * cam_acc.size());
         cost2[0] = st.pin_ne.p[cam_acc.size()];
         cost2[1] = st.pin_ne.p[cam_acc.size() + 1];
+        e.active = 0;
     }
-    bool queue_schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
-                     int* nfail) {
+    bool prep_schur(double radius, bool init_scale, std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) {
         const Structure& s = st.s;
         const int n = s.nsh;
         S.assign(static_cast<size_t>(n) * n, 0.0);
@@ -301,9 +347,17 @@ struct HipBackend final : Backend {
         *gmax_priv = 0.0;
         *nfail = 0;
         if (s.n_views == 0) return false;
+        st.pin_lmp.p[0] = radius;
+        st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
+        return true;
+    }
+    void enqueue_schur(bool constrained) {
+        const Structure& s = st.s;
+        const int n = s.nsh;
+        st.lmp.upload(st.pin_lmp.p, 2, e.stream);
         CBA_HIP(hipMemsetAsync(st.nfail.p, 0, sizeof(int32_t), e.stream));
         hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, radius, init_scale ? 1 : 0, constrained ? 1 : 0,
+                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.lmp.p, constrained ? 1 : 0,
                            e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                            st.view_gmax.p, st.nfail.p);
         hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
@@ -318,12 +372,8 @@ struct HipBackend final : Backend {
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
                            st.schur_pack.p + sw + n);
         CBA_HIP(hipGetLastError());
-        const size_t n_pack = static_cast<size_t>(sw) + n + 1;
-        st.pin.reserve(n_pack);
-        st.pin_i.reserve(1);
-        st.schur_pack.download(st.pin.p, n_pack, e.stream);
+        st.schur_pack.download(st.pin.p, static_cast<size_t>(sw) + n + 1, e.stream);
         st.nfail.download(st.pin_i.p, 1, e.stream);
-        return true;
     }
     void collect_schur(std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) {
         const Structure& s = st.s;
@@ -350,28 +400,59 @@ struct HipBackend final : Backend {
                 }
             }
     }
+
+    void normal_eq(double huber, std::vector<double>& cam_acc, double cost2[2]) override {  // covariance / cost paths: plain launches
+        if (!prep_normal_eq(cam_acc, cost2)) return;
+        enqueue_normal_eq(huber);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        collect_normal_eq(cam_acc, cost2);
+    }
+    void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
+               int* nfail) override {
+        if (!prep_schur(radius, init_scale, S, g, gmax_priv, nfail)) return;
+        run_stage(st.g_schur, 0.0, constrained, [&] { enqueue_schur(constrained); });
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        collect_schur(S, g, gmax_priv, nfail);
+    }
+    // a new linearisation: every kernel of both stages and both result copies in one graph, ONE stream synchronisation
+    void normal_eq_schur(double huber, std::vector<double>& cam_acc, double cost2[2], double radius, bool init_scale, bool constrained,
+                         std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) override {
+        const bool q1 = prep_normal_eq(cam_acc, cost2);
+        const bool q2 = prep_schur(radius, init_scale, S, g, gmax_priv, nfail);
+        if (!q1 && !q2) return;
+        run_stage(st.g_new, huber, constrained, [&] {
+            if (q1) enqueue_normal_eq(huber);
+            if (q2) enqueue_schur(constrained);
+        });
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        if (q1) collect_normal_eq(cam_acc, cost2);
+        if (q2) collect_schur(S, g, gmax_priv, nfail);
+    }
     void trial(const double* delta_sh, double huber, TrialStats* out) override {
         const Structure& s = st.s;
         *out = TrialStats();
         if (s.n_blocks == 0) return;
-        e.delta_sh.upload(delta_sh, s.nsh, e.stream);
-        if (s.n_views > 0) {
-            hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                               st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
-                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
-            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
-                               static_cast<const double*>(nullptr), st.small_out.p + 8);
-        }
-        // cost at the trial point (Mode R); blk_s / blk_w of the ACCEPTED point stay in blk_acc / blk_w
-        launch_block_consts(e, 1);
-        launch_resid_trial(e, huber);
-        CBA_HIP(hipGetLastError());
-        st.pin.reserve(26);
-        st.small_out.download(st.pin.p, 24, e.stream);
-        e.scalar_out.download(st.pin.p + 24, 2, e.stream);
+        std::memcpy(st.pin_delta.p, delta_sh, sizeof(double) * s.nsh);
+        run_stage(st.g_trial, huber, false, [&] {
+            e.delta_sh.upload(st.pin_delta.p, s.nsh, e.stream);
+            if (s.n_views > 0) {
+                hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                                   st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
+                                   e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+                hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
+                                   static_cast<const double*>(nullptr), st.small_out.p + 8);
+            }
+            // cost at the trial point (Mode R); blk_s / blk_w of the ACCEPTED point stay in blk_acc / blk_w
+            launch_block_consts(e, 1);
+            launch_resid_trial(e, huber);
+            CBA_HIP(hipGetLastError());
+            st.small_out.download(st.pin_tr.p, 24, e.stream);
+            e.scalar_out.download(st.pin_tr.p + 24, 2, e.stream);
+        });
         CBA_HIP(hipStreamSynchronize(e.stream));
-        const double* h = st.pin.p;
-        const double* c2 = st.pin.p + 24;
+        e.active = 1;
+        const double* h = st.pin_tr.p;
+        const double* c2 = st.pin_tr.p + 24;
         out->step2 = s.n_views > 0 ? h[8] : 0.0;
         out->xnorm2 = s.n_views > 0 ? h[9] : 0.0;
         out->gd = s.n_views > 0 ? h[10] : 0.0;
@@ -445,6 +526,19 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d) {
     st->gvec_partial.alloc(static_cast<size_t>(st->n_vchunks) * s.nsh);
     st->small_out.alloc(32);
     st->small_out.zero(e.stream);
+    // pinned staging of everything a captured stage copies (sizes are fixed per problem: nothing is allocated in a capture)
+    st->pin.reserve(static_cast<size_t>(st->n_pairs) * 4096 + s.nsh + 8);
+    st->pin_ne.reserve(static_cast<size_t>(s.n_cams) * s.NACC + 2);
+    st->pin_tr.reserve(32);
+    st->pin_i.reserve(1);
+    st->pin_lmp.reserve(2);
+    st->pin_delta.reserve(std::max(1, s.nsh));
+    st->lmp.alloc(2);
+    if (const char* env = std::getenv("CBA_LM_GRAPH")) {
+        const int v = std::atoi(env);
+        st->graphs_ok = v != 0;
+        st->graph_after = v > 1 ? v : (v == 1 ? 0 : st->graph_after);
+    }
     e.blk_w.alloc(std::max(1, s.n_blocks));
     e.cam_acc.alloc(static_cast<size_t>(s.n_cams) * s.NACC);
     e.view_L.alloc(nv * 36);
