@@ -245,9 +245,9 @@ struct HipLMState {
     };
     GraphSlot g_new, g_schur, g_trial;
     bool graphs_ok = true;
-    int graph_after = 24; // capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
-                          // than a handful of iterations (or a handle that is solved again), so a stage runs as plain
-                          // launches until it has been used this many times with the same key (CBA_LM_GRAPH=<n>, 0 = never)
+    int graph_after = 200;// capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
+                          // than a solve, so a stage runs as plain launches until it has been used this many times with
+                          // the same key — i.e. on handles that are solved again and again (CBA_LM_GRAPH=<n>, 1 = at once, 0 = never)
     DevBuf<double> lmp;          // device [radius, init_scale]
     PinnedBuf<double> pin_lmp, pin_delta;
 };
@@ -534,6 +534,12 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d) {
     st->pin_lmp.reserve(2);
     st->pin_delta.reserve(std::max(1, s.nsh));
     st->lmp.alloc(2);
+    {   // ROCm loads a translation unit's code object on the first use of one of its kernels (milliseconds for the
+        // template-heavy ones): touch both units here so that the first solve does not pay for it
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_schur_view));
+        warm_reproj_kernels();
+    }
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);
         st->graphs_ok = v != 0;
@@ -600,6 +606,29 @@ void rccl_destroy(Engine& e) {
 static LMDriver make_driver(Engine& e, HipBackend& be) {
     AllReduce ar = [&e](double* buf, int64_t n) { engine_allreduce(e, buf, n); };
     return LMDriver(lm_state(e)->s, be, e.h_intr, e.h_cam, e.h_view, e.h_target, ar, e.n_ranks, e.rank);
+}
+
+// One throw-away pass through the three LM stages at handle creation: the first launch of every kernel carries a
+// one-time cost on ROCm (code-object load, ~0.1-0.3 ms of per-kernel set-up) that added ~8 ms to the first solve of
+// a small problem; a handle that exists has paid it.  Results are discarded (every solve re-evaluates from the parameters).
+void warm_lm(Engine& e) {
+    HipBackend be(e, *lm_state(e));
+    const Structure& s = lm_state(e)->s;
+    if (s.n_blocks == 0) return;
+    std::vector<double> cam_acc, S, g, d(std::max(1, s.nsh), 0.0);
+    double c2[2], gm = 0.0;
+    int nf = 0;
+    std::vector<int32_t> fixed(s.n_views, 0);
+    be.set_view_fixed(fixed);
+    be.upload_shared(0, e.h_intr.data(), e.h_cam.data(), e.h_target.data());
+    be.normal_eq_schur(1.0, cam_acc, c2, 1e4, true, false, S, g, &gm, &nf);
+    std::vector<double> S2, g2;
+    be.schur(1e4, false, false, S2, g2, &gm, &nf);
+    be.upload_shared(1, e.h_intr.data(), e.h_cam.data(), e.h_target.data());
+    TrialStats ts;
+    be.trial(d.data(), 1.0, &ts);
+    lm_state(e)->g_new.uses = lm_state(e)->g_schur.uses = lm_state(e)->g_trial.uses = 0;
+    CBA_HIP(hipStreamSynchronize(e.stream));
 }
 
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {

@@ -218,6 +218,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     e.scalar_out.alloc(8);
     CBA_HIP(hipStreamSynchronize(e.stream));
     init_lm_state(e, d);
+    warm_lm(e);
 }
 
 extern "C" {

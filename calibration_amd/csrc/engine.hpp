@@ -180,12 +180,14 @@ void ensure_f32_buffers(Engine& e);                      // fp32 copies of the o
 void launch_block_consts(Engine& e, int which);         // params[which] -> bc, sd
 void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
 void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2
+void warm_reproj_kernels();                              // forces the code object of kernels_reproj.hip to load
 void launch_normal_eq(Engine& e);                       // Mode B: blk_acc[b] = [H | g | s]
 void launch_cost(Engine& e, double huber_delta);        // scalar_out[0] = 1/2 sum rho(blk_s)
 
 // backend_hip.hip
 void init_lm_state(Engine& e, const cba_reproj_problem& d);
 void destroy_lm_state(Engine& e);
+void warm_lm(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
 void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
 int64_t covariance_dim(const Engine& e);

@@ -498,6 +498,11 @@ static void launch_ne(Engine& e, unsigned g) {
     }
 }
 
+void warm_reproj_kernels() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_tile_sum));
+}
+
 void launch_normal_eq(Engine& e) {
     if (e.n_tilesB == 0) return;
     const unsigned g = blocks_for(e.n_tilesB, 4);
