@@ -96,14 +96,16 @@ def main():
     achieved = bytes_per_obs * n_obs / (ms_kernel * 1e-3) / 1e9
     # HBM traffic of one k_eval launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate
     # rocprofv3 --pmc runs of this same command; gfx950 FETCH_SIZE correction applied), same unit as `achieved`
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_bytes = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_k_eval.json")
     if os.path.exists(pmc_path) and args.views == 1000 and args.grid == 100:
         pmc = json.load(open(pmc_path))
-        traffic = pmc["hbm_bytes_per_launch"] / (ms_kernel * 1e-3) / 1e9
+        traffic_bytes = pmc["hbm_bytes_per_launch"]
+        traffic = traffic_bytes / (ms_kernel * 1e-3) / 1e9
         traffic_src = "profiles/pmc_k_eval.json"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_bytes_per_launch": traffic_bytes, "algorithmic_bytes_per_launch": bytes_per_obs * n_obs,
                 "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
