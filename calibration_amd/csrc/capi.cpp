@@ -214,6 +214,8 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     if (d.chain == CBA_CHAIN_BUNDLE) e.aux.upload(d.blk_b_T_g, static_cast<size_t>(d.n_blocks) * 12, e.stream);
     e.partial.alloc(static_cast<size_t>(e.n_tilesB) * e.NACC);
     e.blk_acc.alloc(static_cast<size_t>(d.n_blocks) * e.NACC);
+    if (d.chain != CBA_CHAIN_INTRINSIC) e.blk_mom.alloc(static_cast<size_t>(std::max(1, d.n_blocks)) * 256);
+    if (const char* env = std::getenv("CBA_MODEB_MOMENTS")) e.modeb_moments = std::atoi(env);
     e.blk_s.alloc(d.n_blocks);
     e.scalar_out.alloc(8);
     CBA_HIP(hipStreamSynchronize(e.stream));

@@ -170,16 +170,16 @@ CBA_HD void mat3_tvec_t(const T* A, const T* x, T* y) {  // y = A^T x
     for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
 }
 
-// Residual + Jacobian rows.  Ju/Jv: LocalCols<CHAIN,MODEL>::value entries each.
-template <int CHAIN, int MODEL, typename T>
-CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, T* r, T* Ju, T* Jv) {
-    constexpr int OI = CHAIN == CH_INTRINSIC ? 6 : 12;  // offset of the intrinsics columns
+// Everything of one observation that does not depend on the pose chain: residual r, the camera-frame point P,
+// du = d u / d P and dv = d v / d P (3 each), and the intrinsics columns Jui / Jvi (IntrSize<MODEL> each).
+template <int MODEL, typename T>
+CBA_HD void reproj_core(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, T* r, T* P, T* du, T* dv, T* Jui, T* Jvi) {
     const T fx = intr[0], fy = intr[1], skew = intr[4];
     const T k1 = intr[5], k2 = intr[6], k3 = intr[7], p1 = intr[8], p2 = intr[9];
 
-    const T P[3] = {X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0],
-                    X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1],
-                    X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2]};
+    P[0] = X * bc[BC_M1] + Y * bc[BC_M2] + bc[BC_P0];
+    P[1] = X * bc[BC_M1 + 1] + Y * bc[BC_M2 + 1] + bc[BC_P0 + 1];
+    P[2] = X * bc[BC_M1 + 2] + Y * bc[BC_M2 + 2] + bc[BC_P0 + 2];
     // (x, y) = normalised coordinates fed to Brown-Conrady and d(x,y)/dP rows gx, gy
     T x, y, gx[3], gy[3], m0x = T(0), m0y = T(0), mx = T(0), my = T(0), is = T(0);
     if (MODEL == CAM_PINHOLE_BC) {
@@ -215,8 +215,44 @@ CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo
     const T ux = fx * dxdx + skew * dxdy, uy = fx * dxdy + skew * dydy;
     const T vx = fy * dxdy, vy = fy * dydy;
     // d(u,v)/dP
-    T du[3], dv[3];
     for (int i = 0; i < 3; ++i) { du[i] = ux * gx[i] + uy * gy[i]; dv[i] = vx * gx[i] + vy * gy[i]; }
+
+    // ---- intrinsics [fx fy cx cy skew k1 k2 k3 p1 p2 (tau_x tau_y)] ----
+    const T r4 = r2 * r2, r6 = r4 * r2;
+    const T t1x = T(2) * xy, t1y = r2 + T(2) * yy;  // d(xd,yd)/dp1
+    const T t2x = r2 + T(2) * xx, t2y = T(2) * xy;  // d(xd,yd)/dp2
+    Jui[0] = xd + m0x; Jvi[0] = T(0);
+    Jui[1] = T(0);     Jvi[1] = yd + m0y;
+    Jui[2] = T(1);     Jvi[2] = T(0);
+    Jui[3] = T(0);     Jvi[3] = T(1);
+    Jui[4] = yd + m0y; Jvi[4] = T(0);
+    const T gu = fx * x + skew * y, gv = fy * y;
+    Jui[5] = gu * r2;  Jvi[5] = gv * r2;
+    Jui[6] = gu * r4;  Jvi[6] = gv * r4;
+    Jui[7] = gu * r6;  Jvi[7] = gv * r6;
+    Jui[8] = fx * t1x + skew * t1y; Jvi[8] = fy * t1y;
+    Jui[9] = fx * t2x + skew * t2y; Jvi[9] = fy * t2y;
+    if (MODEL == CAM_SCHEIMPFLUG) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const T* D = sd + (k == 0 ? SD_DX : SD_DY);
+            const T* dm0 = sd + (k == 0 ? SD_DM0X : SD_DM0Y);
+            const T dnP = D[2] * P[0] + D[5] * P[1] + D[8] * P[2];
+            const T dmx = ((D[0] * P[0] + D[3] * P[1] + D[6] * P[2]) - mx * dnP) * is;
+            const T dmy = ((D[1] * P[0] + D[4] * P[1] + D[7] * P[2]) - my * dnP) * is;
+            const T dx = dmx - dm0[0], dy = dmy - dm0[1];
+            Jui[10 + k] = ux * dx + uy * dy + fx * dm0[0] + skew * dm0[1];
+            Jvi[10 + k] = vx * dx + vy * dy + fy * dm0[1];
+        }
+    }
+}
+
+// Residual + Jacobian rows.  Ju/Jv: LocalCols<CHAIN,MODEL>::value entries each, [pose A d(3) t(3) | pose B d(3) t(3) | intr].
+template <int CHAIN, int MODEL, typename T>
+CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, T* r, T* Ju, T* Jv) {
+    constexpr int OI = CHAIN == CH_INTRINSIC ? 6 : 12;  // offset of the intrinsics columns
+    T P[3], du[3], dv[3];
+    reproj_core<MODEL, T>(bc, intr, sd, X, Y, uo, vo, r, P, du, dv, Ju + OI, Jv + OI);
 
     // ---- pose A: dP/d(delta_A) = -2 M [c]x, dP/d(t_A) = M,  c = X a1 + Y a2 ----
     const T c[3] = {X * bc[BC_A1] + Y * bc[BC_A2], X * bc[BC_A1 + 1] + Y * bc[BC_A2 + 1],
@@ -245,35 +281,162 @@ CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo
         cross3t(dv, P, h); mat3_tvec_t(bc + BC_N, h, hn); mat3_tvec_t(bc + BC_N, dv, dn);
         for (int i = 0; i < 3; ++i) { Jv[6 + i] = T(2) * hn[i]; Jv[9 + i] = -dn[i]; }
     }
+}
 
-    // ---- intrinsics [fx fy cx cy skew k1 k2 k3 p1 p2 (tau_x tau_y)] ----
-    const T r4 = r2 * r2, r6 = r4 * r2;
-    const T t1x = T(2) * xy, t1y = r2 + T(2) * yy;  // d(xd,yd)/dp1
-    const T t2x = r2 + T(2) * xx, t2y = T(2) * xy;  // d(xd,yd)/dp2
-    Ju[OI + 0] = xd + m0x; Jv[OI + 0] = T(0);
-    Ju[OI + 1] = T(0);     Jv[OI + 1] = yd + m0y;
-    Ju[OI + 2] = T(1);     Jv[OI + 2] = T(0);
-    Ju[OI + 3] = T(0);     Jv[OI + 3] = T(1);
-    Ju[OI + 4] = yd + m0y; Jv[OI + 4] = T(0);
-    const T gu = fx * x + skew * y, gv = fy * y;
-    Ju[OI + 5] = gu * r2;  Jv[OI + 5] = gv * r2;
-    Ju[OI + 6] = gu * r4;  Jv[OI + 6] = gv * r4;
-    Ju[OI + 7] = gu * r6;  Jv[OI + 7] = gv * r6;
-    Ju[OI + 8] = fx * t1x + skew * t1y; Jv[OI + 8] = fy * t1y;
-    Ju[OI + 9] = fx * t2x + skew * t2y; Jv[OI + 9] = fy * t2y;
-    if (MODEL == CAM_SCHEIMPFLUG) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const T* D = sd + (k == 0 ? SD_DX : SD_DY);
-            const T* dm0 = sd + (k == 0 ? SD_DM0X : SD_DM0Y);
-            const T dnP = D[2] * P[0] + D[5] * P[1] + D[8] * P[2];
-            const T dmx = ((D[0] * P[0] + D[3] * P[1] + D[6] * P[2]) - mx * dnP) * is;
-            const T dmy = ((D[1] * P[0] + D[4] * P[1] + D[7] * P[2]) - my * dnP) * is;
-            const T dx = dmx - dm0[0], dy = dmy - dm0[1];
-            Ju[OI + 10 + k] = ux * dx + uy * dy + fx * dm0[0] + skew * dm0[1];
-            Jv[OI + 10 + k] = vx * dx + vy * dy + fy * dm0[1];
+// The pose columns of one observation are d(u,v)/dP times a 3 x 12 matrix that is AFFINE in the target point:
+//     [Ju_pose; Jv_pose] = [du; dv]^T (G0 + X G1 + Y G2),      G_a constant over the residual block.
+// (pose A: dP/d(delta_A) = -2 M [X a1 + Y a2]x, dP/d(t_A) = M; pose B, EXTRINSIC: -2 [X m1 + Y m2 + p0 - t_B]x and I;
+// BUNDLE: 2 [X m1 + Y m2 + p0]x N and -N.)  Mode B of the two-pose chains therefore accumulates MOMENTS of
+// Q = du du^T + dv dv^T etc. instead of the 12-column blocks (k_normal_eq_mom), and this routine expands a block's
+// moments into the packed [H | g | s] row.  G[a] is row-major 3 x 12.
+template <int CHAIN>
+CBA_HD void pose_affine_G(const double* bc, double G[3][36]) {
+    for (int a = 0; a < 3; ++a) for (int i = 0; i < 36; ++i) G[a][i] = 0.0;
+    const double* M = bc + BC_M;
+    auto skew_cols = [](const double* v, double* S /*3x3 row-major [v]x*/) {
+        S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
+    };
+    // pose A rotation: -2 M [a_k]x for X (a1) and Y (a2); translation: M (constant)
+    for (int a = 1; a <= 2; ++a) {
+        double S[9], MS[9];
+        skew_cols(bc + (a == 1 ? BC_A1 : BC_A2), S);
+        mat3_mul(M, S, MS);
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + i] = -2.0 * MS[k * 3 + i];
+    }
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[0][k * 12 + 3 + i] = M[k * 3 + i];
+    // pose B
+    const double* vec[3] = {bc + BC_P0, bc + BC_M1, bc + BC_M2};
+    for (int a = 0; a < 3; ++a) {
+        double v[3] = {vec[a][0], vec[a][1], vec[a][2]}, S[9];
+        if (CHAIN == CH_EXTRINSIC) {
+            if (a == 0) for (int k = 0; k < 3; ++k) v[k] -= bc[BC_TB + k];
+            skew_cols(v, S);
+            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + 6 + i] = -2.0 * S[k * 3 + i];
+        } else {
+            double SN[9];
+            skew_cols(v, S);
+            mat3_mul(S, bc + BC_N, SN);
+            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + 6 + i] = 2.0 * SN[k * 3 + i];
         }
     }
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 3; ++i)
+            G[0][k * 12 + 9 + i] = CHAIN == CH_EXTRINSIC ? (k == i ? 1.0 : 0.0) : -bc[BC_N + k * 3 + i];
+}
+
+// moment-row layout of one residual block (PI = intrinsics size):
+//   [ Qm 6x6 | qm 3x3 | Em 3 x 3 x PI | Hii PI(PI+1)/2 | gi PI | s ]
+// Qm[(a,b)][(k,l)] over the pairs (0,0),(0,1),(0,2),(1,1),(1,2),(2,2) of m = (1, X, Y) and of the 3x3 symmetric Q.
+template <int PI>
+struct MomLayout {
+    static constexpr int OFF_Q = 0, OFF_q = 36, OFF_E = 45, OFF_H = 45 + 9 * PI, OFF_G = OFF_H + PI * (PI + 1) / 2, OFF_S = OFF_G + PI,
+                         N = OFF_S + 1;
+};
+CBA_HD int sym3(int k, int l) {  // 00 01 02 11 12 22
+    const int a = k < l ? k : l, b = k < l ? l : k;
+    return a == 0 ? b : (a == 1 ? 2 + b : 5);
+}
+
+// entry e of the packed [H | g | s] row (width NACC, PL = 12 + PI columns) from the block's moments
+template <int PI>
+CBA_HD double mom_expand_entry(const double* mom, const double G[3][36], int e) {
+    using L = MomLayout<PI>;
+    constexpr int PL = 12 + PI, NH = PL * (PL + 1) / 2;
+    if (e == NH + PL) return mom[L::OFF_S];
+    if (e >= NH) {  // gradient
+        const int i = e - NH;
+        if (i >= 12) return mom[L::OFF_G + i - 12];
+        double s = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) s += G[a][k * 12 + i] * mom[L::OFF_q + a * 3 + k];
+        return s;
+    }
+    // (i, j) of the upper triangle, row-major
+    int i = 0, rem = e;
+    while (rem >= PL - i) { rem -= PL - i; ++i; }
+    const int j = i + rem;
+    if (i >= 12) {  // intrinsics-intrinsics
+        const int a = i - 12, b = j - 12;
+        return mom[L::OFF_H + a * PI - a * (a - 1) / 2 + (b - a)];
+    }
+    if (j >= 12) {  // pose-intrinsics
+        double s = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) s += G[a][k * 12 + i] * mom[L::OFF_E + (a * 3 + k) * PI + (j - 12)];
+        return s;
+    }
+    double s = 0.0;  // pose-pose
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double* Q = mom + L::OFF_Q + 6 * sym3(a, b);
+            for (int k = 0; k < 3; ++k) {
+                const double gk = G[a][k * 12 + i];
+                if (gk == 0.0) continue;
+                for (int l = 0; l < 3; ++l) s += gk * Q[sym3(k, l)] * G[b][l * 12 + j];
+            }
+        }
+    return s;
+}
+
+// One observation's contribution to the entries e (e % NPARTS == PART, kept at acc[e / NPARTS]) of the moment row.
+// u row of the intrinsics block has no fy / cy entry, v row no fx / cx / skew entry (as in RowMask of Mode B).
+template <int MODEL, int NPARTS, int PART, typename T>
+CBA_HD void mom_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, double* acc) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    using L = MomLayout<PI>;
+    T rt[2], Pt[3], dut[3], dvt[3], Juit[PI], Jvit[PI];
+    reproj_core<MODEL, T>(bc, intr, sd, X, Y, uo, vo, rt, Pt, dut, dvt, Juit, Jvit);
+    double du[3], dv[3], Jui[PI], Jvi[PI];
+    const double ru = rt[0], rv = rt[1];
+    for (int k = 0; k < 3; ++k) { du[k] = dut[k]; dv[k] = dvt[k]; }
+    for (int j = 0; j < PI; ++j) { Jui[j] = Juit[j]; Jvi[j] = Jvit[j]; }
+    const double x = X, y = Y;
+    const double m[3] = {1.0, x, y};
+    const double mm[6] = {1.0, x, y, x * x, x * y, y * y};
+#define CBA_ACC(E, VALUE) if (((E) % NPARTS) == PART) acc[(E) / NPARTS] += (VALUE)
+#define CBA_FMA(E, A, B) if (((E) % NPARTS) == PART) acc[(E) / NPARTS] = __builtin_fma((A), (B), acc[(E) / NPARTS])
+    {   // Q = du du^T + dv dv^T and its six moments
+        int kl = 0;
+        for (int k = 0; k < 3; ++k)
+            for (int l = k; l < 3; ++l, ++kl) {
+                const double q = __builtin_fma(dv[k], dv[l], du[k] * du[l]);
+                CBA_ACC(L::OFF_Q + kl, q);
+                for (int a = 1; a < 6; ++a) CBA_FMA(L::OFF_Q + a * 6 + kl, mm[a], q);
+            }
+    }
+    for (int k = 0; k < 3; ++k) {  // q = du r_u + dv r_v
+        const double q = __builtin_fma(dv[k], rv, du[k] * ru);
+        CBA_ACC(L::OFF_q + k, q);
+        CBA_FMA(L::OFF_q + 3 + k, m[1], q);
+        CBA_FMA(L::OFF_q + 6 + k, m[2], q);
+    }
+    for (int k = 0; k < 3; ++k)  // E = du Jui^T + dv Jvi^T
+        for (int j = 0; j < PI; ++j) {
+            const bool hu = !(j == 1 || j == 3), hv = !(j == 0 || j == 2 || j == 4);
+            double ekj = 0.0;
+            if (hu) ekj = du[k] * Jui[j];
+            if (hv) ekj = __builtin_fma(dv[k], Jvi[j], ekj);
+            CBA_ACC(L::OFF_E + k * PI + j, ekj);
+            CBA_FMA(L::OFF_E + (3 + k) * PI + j, m[1], ekj);
+            CBA_FMA(L::OFF_E + (6 + k) * PI + j, m[2], ekj);
+        }
+    {   // intrinsics-intrinsics, gradient, |r|^2
+        int e = L::OFF_H;
+        for (int a = 0; a < PI; ++a)
+            for (int b = a; b < PI; ++b, ++e) {
+                const bool hu = !(a == 1 || a == 3) && !(b == 1 || b == 3), hv = !(a == 0 || a == 2 || a == 4) && !(b == 0 || b == 2 || b == 4);
+                if (hu) CBA_FMA(e, Jui[a], Jui[b]);
+                if (hv) CBA_FMA(e, Jvi[a], Jvi[b]);
+            }
+        for (int a = 0; a < PI; ++a) {
+            if (!(a == 1 || a == 3)) CBA_FMA(L::OFF_G + a, Jui[a], ru);
+            if (!(a == 0 || a == 2 || a == 4)) CBA_FMA(L::OFF_G + a, Jvi[a], rv);
+        }
+        CBA_FMA(L::OFF_S, ru, ru);
+        CBA_FMA(L::OFF_S, rv, rv);
+    }
+#undef CBA_ACC
+#undef CBA_FMA
 }
 
 // ---- Huber (ceres::HuberLoss + Corrector with rho'' <= 0): weight = rho'(s), rho(s) ------------

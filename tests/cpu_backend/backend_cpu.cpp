@@ -82,6 +82,25 @@ struct CpuBackend final : Backend {
             }
         }
     }
+    // the same blocks through the moment form of the two-pose chains (reproj_math.hpp: mom_point / pose_affine_G / mom_expand_entry)
+    template <int CHAIN, int MODEL>
+    void mode_b_moments(int which) {
+        constexpr int PI = IntrSize<MODEL>::value;
+        constexpr int NMOM = MomLayout<PI>::N;
+        for (int b = 0; b < s.n_blocks; ++b) {
+            double mom[NMOM];
+            for (int e = 0; e < NMOM; ++e) mom[e] = 0.0;
+            const int c = s.blk_cam[b];
+            for (int64_t i = s.blk_offset[b]; i < s.blk_offset[b + 1]; ++i)
+                mom_point<MODEL, 1, 0, double>(&bc[static_cast<size_t>(b) * BC_SIZE], &intr[which][static_cast<size_t>(c) * s.PI],
+                                               &sd[static_cast<size_t>(c) * SD_SIZE], d.X[i], d.Y[i], d.u[i], d.v[i], mom);
+            double G[3][36];
+            pose_affine_G<CHAIN>(&bc[static_cast<size_t>(b) * BC_SIZE], G);
+            double* acc = &blk_acc[static_cast<size_t>(b) * s.NACC];
+            for (int e = 0; e < s.NACC; ++e) acc[e] = mom_expand_entry<PI>(mom, G, e);
+        }
+    }
+    bool use_moments = false;
     double block_s(int which, int b) {
         const int c = s.blk_cam[b];
         double ss = 0;
@@ -100,10 +119,10 @@ struct CpuBackend final : Backend {
         switch (s.chain * 2 + s.model) {
             case 0: mode_b<CH_INTRINSIC, CAM_PINHOLE_BC>(0); break;
             case 1: mode_b<CH_INTRINSIC, CAM_SCHEIMPFLUG>(0); break;
-            case 2: mode_b<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); break;
-            case 3: mode_b<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); break;
-            case 4: mode_b<CH_BUNDLE, CAM_PINHOLE_BC>(0); break;
-            default: mode_b<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); break;
+            case 2: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); else mode_b<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); break;
+            case 3: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); else mode_b<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); break;
+            case 4: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_PINHOLE_BC>(0); else mode_b<CH_BUNDLE, CAM_PINHOLE_BC>(0); break;
+            default: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); else mode_b<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); break;
         }
         cost2[0] = cost2[1] = 0;
         cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
@@ -236,6 +255,21 @@ int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allre
         LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, ar, n_ranks, rank);
         drv.solve(*o, out);
         store(*d, ss);
+    });
+}
+
+// per-block packed [H | g | s] rows at the problem's parameters, through the direct (moments = 0) or the moment form
+int hm_reproj_block_normal_eq(const cba_reproj_problem* d, int moments, double* out) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        be.use_moments = moments != 0;
+        be.upload_shared(0, ss.intr.data(), ss.cam.data(), ss.target.data());
+        std::vector<double> cam_acc;
+        double c2[2];
+        be.normal_eq(1.0, cam_acc, c2);
+        std::memcpy(out, be.blk_acc.data(), sizeof(double) * be.blk_acc.size());
     });
 }
 

@@ -530,3 +530,28 @@ def test_planar_seed_matches_svd_restatement(hostmath, noise):
     p = np.ones(7)
     hostmath.hm_planar_seed(3, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(np.ascontiguousarray(cam[:5])), dptr(p))
     assert np.array_equal(p, [1, 0, 0, 0, 0, 0, 0])  # < 4 points: identity (planarpose_linear.cpp:55-57)
+
+
+# ---- Mode B of the two-pose chains through moments: identical block normal equations ------------------------------------------
+@pytest.mark.parametrize("kind,model", [("ext", 0), ("ext", 1), ("bundle", 0), ("bundle", 1)])
+def test_moment_form_reproduces_the_direct_block_normal_equations(hostmath, kind, model):
+    sc = (synth.scene_extrinsics(5, 3, model=model, noise_px=0.3) if kind == "ext"
+          else synth.scene_bundle(9, 2, model=model, distortion=True, noise_px=0.3))
+    sc.flat.intr[...] = sc.gt_intr * (1 + 0.01 * np.random.default_rng(2).uniform(-1, 1, sc.gt_intr.shape))
+    d = sc.flat.struct()
+    p = helpers.local_cols(sc.flat)
+    nacc = p * (p + 1) // 2 + p + 1
+    a, b = np.zeros((sc.flat.n_blocks, nacc)), np.zeros((sc.flat.n_blocks, nacc))
+    assert hostmath.hm_reproj_block_normal_eq(C.byref(d), 0, dptr(a)) == 0
+    assert hostmath.hm_reproj_block_normal_eq(C.byref(d), 1, dptr(b)) == 0
+    for ra, rb in zip(a, b):
+        H = np.zeros((p, p))
+        H[np.triu_indices(p)] = ra[:p * (p + 1) // 2]
+        dg = np.sqrt(np.diag(H))
+        Hb = np.zeros((p, p))
+        Hb[np.triu_indices(p)] = rb[:p * (p + 1) // 2]
+        sc_ = np.outer(dg, dg)
+        nz = sc_ > 0
+        assert (np.abs(H - Hb)[nz] / sc_[nz]).max() <= 1e-11
+        ga, gb = ra[p * (p + 1) // 2:-1], rb[p * (p + 1) // 2:-1]
+        assert np.abs(ga - gb).max() <= 1e-10 * np.abs(ga).max() and abs(ra[-1] - rb[-1]) <= 1e-12 * ra[-1]
