@@ -555,3 +555,16 @@ def test_moment_form_reproduces_the_direct_block_normal_equations(hostmath, kind
         assert (np.abs(H - Hb)[nz] / sc_[nz]).max() <= 1e-11
         ga, gb = ra[p * (p + 1) // 2:-1], rb[p * (p + 1) // 2:-1]
         assert np.abs(ga - gb).max() <= 1e-10 * np.abs(ga).max() and abs(ra[-1] - rb[-1]) <= 1e-12 * ra[-1]
+
+
+def test_semidlt_too_few_observations_is_runtime_error(hostmath):
+    """4 views x 1 point = 4 observations < 8: fit_distortion_full returns nullopt (distortion.h:235-238), the functor fails,
+    Ceres reports FAILURE and solve_full throws std::runtime_error("Failed to compute distortion parameters") (:176-179)."""
+    d, _, _ = helpers.semidlt_scene(4, noise=0.0, nr=2)
+    off = np.arange(5, dtype=np.int64)
+    idx = d["off"][:-1]
+    d1 = dict(d, off=off, X=np.ascontiguousarray(d["X"][idx]), Y=np.ascontiguousarray(d["Y"][idx]), u=np.ascontiguousarray(d["u"][idx]),
+              v=np.ascontiguousarray(d["v"][idx]))
+    st = helpers.semidlt_solve(hostmath.hm_semidlt_solve, d1, 2, options(), want_cov=False)
+    assert st[0] != 0 and b"Failed to compute distortion parameters" in hostmath.hm_semidlt_last_error()
+    assert st[3].termination == capi.TERM_FAILURE and not st[3].success
