@@ -137,6 +137,66 @@ CBA_HD void axxb_point(const double* RX, const double* tX, const double* RA, con
 
 // One pair's contribution to [H upper (21) | g (6) | cost (1) | count (1)] with per-pair Huber
 // (handeye.cpp:48-55: every pair has its own HuberLoss).
+// Tsai-Lenz all-pairs sums (estimate_rotation_allpairs_weighted / estimate_translation_allpairs_weighted,
+// src/estimation/linear/handeyedlt.cpp:84-124) of ONE motion pair, into acc[0..5] (upper triangle of the 3x3 normal matrix),
+// acc[6..8] (right-hand side), acc[9] (pair count).
+//   mode 0 (rotation):    rows skew(alpha + beta), rhs beta - alpha        alpha = log A, beta = log B
+//   mode 1 (translation): rows R_A - I,            rhs R_X t_B - t_A
+CBA_HD void tsai_lenz_accumulate(int mode, const double* RA, const double* RB, const double* tA, const double* tB, const double* RX,
+                                 double* acc) {
+    double M[9], d[3];
+    if (mode == 0) {
+        double al[3], be[3];
+        log_so3(RA, al);
+        log_so3(RB, be);
+        const double s[3] = {al[0] + be[0], al[1] + be[1], al[2] + be[2]};
+        M[0] = 0; M[1] = -s[2]; M[2] = s[1]; M[3] = s[2]; M[4] = 0; M[5] = -s[0]; M[6] = -s[1]; M[7] = s[0]; M[8] = 0;
+        for (int k = 0; k < 3; ++k) d[k] = be[k] - al[k];
+    } else {
+        for (int k = 0; k < 9; ++k) M[k] = RA[k] - ((k % 4 == 0) ? 1.0 : 0.0);
+        double rtb[3];
+        mat3_vec(RX, tB, rtb);
+        for (int k = 0; k < 3; ++k) d[k] = rtb[k] - tA[k];
+    }
+    int e = 0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b) acc[e++] += M[a] * M[b] + M[3 + a] * M[3 + b] + M[6 + a] * M[6 + b];
+    for (int a = 0; a < 3; ++a) acc[6 + a] += M[a] * d[0] + M[3 + a] * d[1] + M[6 + a] * d[2];
+    acc[9] += 1.0;
+}
+
+// ridge_llsq (se3_utils.h:57-63): (A^T A + lambda I) x = A^T b from the packed sums above (Eigen LDLT -> Cholesky, SPD)
+CBA_HD bool tsai_lenz_solve(const double* acc, double lambda, double* x) {
+    double A[9] = {acc[0] + lambda, acc[1], acc[2], acc[1], acc[3] + lambda, acc[4], acc[2], acc[4], acc[5] + lambda};
+    if (!(A[0] > 0.0)) return false;
+    // 3x3 Cholesky
+    const double l00 = sqrt(A[0]), l10 = A[3] / l00, l20 = A[6] / l00;
+    const double d1 = A[4] - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double l11 = sqrt(d1), l21 = (A[7] - l20 * l10) / l11;
+    const double d2 = A[8] - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    const double l22 = sqrt(d2);
+    const double y0 = acc[6] / l00, y1 = (acc[7] - l10 * y0) / l11, y2 = (acc[8] - l20 * y0 - l21 * y1) / l22;
+    x[2] = y2 / l22;
+    x[1] = (y1 - l21 * x[2]) / l11;
+    x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+    return true;
+}
+
+// exp_so3 (se3_utils.h:42-51), row-major
+CBA_HD void exp_so3(const double* w, double* R) {
+    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (th < 1e-12) return;
+    const double a[3] = {w[0] / th, w[1] / th, w[2] / th};
+    const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+    double K2[9];
+    mat3_mul(K, K, K2);
+    const double s = sin(th), c = 1.0 - cos(th);
+    for (int k = 0; k < 9; ++k) R[k] += s * K[k] + c * K2[k];
+}
+
 constexpr int AXXB_NACC = 29;
 CBA_HD void axxb_accumulate(const double* r, const double* J, double huber_delta, double* acc) {
     double s = 0.0;

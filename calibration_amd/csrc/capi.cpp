@@ -643,6 +643,24 @@ cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, c
     });
 }
 
+cba_status cba_estimate_handeye_dlt(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target, double min_angle_deg,
+                                    double* g_T_c) {
+    return guarded([&] {
+        if (!g_T_c) throw std::invalid_argument("null argument");
+        if (n_poses < 2 || !base_T_gripper || !cam_T_target) throw std::runtime_error("Inconsistent hand-eye input sizes");
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        handeye_dlt(n_poses, base_T_gripper, cam_T_target, min_angle_deg, g_T_c, 0);
+    });
+}
+
+cba_status cba_estimate_and_optimize_handeye(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                             double min_angle_deg, double* g_T_c, const cba_options* opts, cba_summary* summary,
+                                             double* cov) {
+    const cba_status st = cba_estimate_handeye_dlt(n_poses, base_T_gripper, cam_T_target, min_angle_deg, g_T_c);
+    if (st != CBA_OK) return st;
+    return cba_optimize_handeye(n_poses, base_T_gripper, cam_T_target, g_T_c, opts, summary, cov);
+}
+
 cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
                                           const double* u, const double* v, const double* kmtx5, int32_t num_radial,
                                           double* pose7, const cba_options* opts, cba_summary* summaries, double* distortion,

@@ -209,6 +209,7 @@ void semidlt_solve(int n_views, const int64_t* view_offset, const double* X, con
                    double* distortion, double* view_errors, double* cov, int device);
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, double* pose7, int device);
+void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device);
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
                    double* cov, int device);
 

@@ -8,10 +8,14 @@
 // two-level sum over workgroups (no atomics; bitwise reproducible).  Compute-bound: ~1.2 kFLOP per pair.
 #include "engine.hpp"
 #include "handeye_core.hpp"
+#include "seed_math.hpp"
 #include "wave_reduce.hpp"
 
 namespace cba {
 
+// MODE 0: the AX = XB residual blocks of optimize_handeye; MODE 1 / 2: the rotation / translation sums of the Tsai-Lenz
+// all-pairs seed estimate_handeye_dlt (handeyedlt.cpp:84-137) — same pair enumeration, same filter, same reduction.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_axxb(int n, const double* __restrict__ poses /*[n][24]: Rb tb Rc tc*/,
                                               const double* __restrict__ X /*RX(9) tX(3)*/, double min_angle,
                                               double axis_eps, double huber_delta, double* __restrict__ partial) {
@@ -26,9 +30,13 @@ __global__ __launch_bounds__(256) void k_axxb(int n, const double* __restrict__ 
         const double* pj = poses + 24 * static_cast<int64_t>(j);
         double RA[9], RB[9], tA[3], tB[3];
         if (motion_pair(pi, pi + 9, pj, pj + 9, pi + 12, pi + 21, pj + 12, pj + 21, min_angle, axis_eps, RA, RB, tA, tB)) {
-            double r[6], J[36];
-            axxb_point(X, X + 9, RA, RB, tA, tB, r, J);
-            axxb_accumulate(r, J, huber_delta, acc);
+            if (MODE == 0) {
+                double r[6], J[36];
+                axxb_point(X, X + 9, RA, RB, tA, tB, r, J);
+                axxb_accumulate(r, J, huber_delta, acc);
+            } else {
+                tsai_lenz_accumulate(MODE - 1, RA, RB, tA, tB, X, acc);
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,7 +107,7 @@ struct HipAxxb final : AxxbEval {
         for (int a = 0; a < 3; ++a) hx[9 + a] = pose7[4 + a];
         X.upload(hx, 12, stream);
         constexpr double kMinAngleDeg = 0.5;  // handeye.cpp:64
-        hipLaunchKernelGGL(k_axxb, grid, dim3(256), 0, stream, n, poses.p, X.p, kMinAngleDeg * 3.14159265358979323846 / 180.0, 1e-3,
+        hipLaunchKernelGGL(k_axxb<0>, grid, dim3(256), 0, stream, n, poses.p, X.p, kMinAngleDeg * 3.14159265358979323846 / 180.0, 1e-3,
                            huber_delta, partial.p);
         hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, stream, n_rows, int64_t{64}, partial.p, partial2.p);
         hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, stream, n_chunks, n_chunks, partial2.p, out.p);
@@ -109,6 +117,38 @@ struct HipAxxb final : AxxbEval {
     }
 };
 }  // namespace
+
+// estimate_handeye_dlt (handeyedlt.cpp:126-137): two passes over all pose pairs on the device (rotation sums, then
+// translation sums at the estimated R_X), two 3x3 ridge solves on the host.  pose7 out.
+void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device) {
+    if (n_poses < 2 || !bTg || !cTt)  // handeyedlt.cpp:56-58
+        throw std::runtime_error("Inconsistent hand-eye input sizes");
+    CBA_HIP(hipSetDevice(device));
+    HipAxxb ev(n_poses, bTg, cTt);
+    const double min_angle = min_angle_deg * 3.14159265358979323846 / 180.0;
+    auto pass = [&](int mode, const double* RX, double* acc) {
+        double hx[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        if (RX) for (int k = 0; k < 9; ++k) hx[k] = RX[k];
+        ev.X.upload(hx, 12, ev.stream);
+        if (mode == 0) hipLaunchKernelGGL(k_axxb<1>, ev.grid, dim3(256), 0, ev.stream, ev.n, ev.poses.p, ev.X.p, min_angle, 1e-3, 0.0, ev.partial.p);
+        else hipLaunchKernelGGL(k_axxb<2>, ev.grid, dim3(256), 0, ev.stream, ev.n, ev.poses.p, ev.X.p, min_angle, 1e-3, 0.0, ev.partial.p);
+        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(ev.n_chunks)), dim3(256), 0, ev.stream, ev.n_rows, int64_t{64}, ev.partial.p, ev.partial2.p);
+        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, ev.stream, ev.n_chunks, ev.n_chunks, ev.partial2.p, ev.out.p);
+        CBA_HIP(hipGetLastError());
+        ev.out.download(acc, AXXB_NACC, ev.stream);
+        CBA_HIP(hipStreamSynchronize(ev.stream));
+    };
+    double acc[AXXB_NACC], w[3], RX[9], t[3];
+    pass(0, nullptr, acc);
+    if (acc[9] < 0.5)  // handeyedlt.cpp:76-79
+        throw std::runtime_error("No valid motion pairs after filtering. Increase motion or relax thresholds.");
+    if (!tsai_lenz_solve(acc, 1e-12, w)) throw std::runtime_error("Tsai-Lenz rotation system is singular");
+    exp_so3(w, RX);
+    pass(1, RX, acc);
+    if (!tsai_lenz_solve(acc, 1e-12, t)) throw std::runtime_error("Tsai-Lenz translation system is singular");
+    seed_rotmat_to_quat(RX, pose7);
+    for (int k = 0; k < 3; ++k) pose7[4 + k] = t[k];
+}
 
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
                    double* cov, int device) {

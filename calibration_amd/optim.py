@@ -492,6 +492,26 @@ def optimize_handeye(base_se3_gripper, camera_se3_target, init_gripper_se3_ref, 
     return HandeyeResult(result_core(s, cov if options.compute_covariance else None), pose_to_matrix(x))
 
 
+def estimate_handeye_dlt(base_se3_gripper, camera_se3_target, min_angle_deg: float = 1.0) -> np.ndarray:
+    """estimate_handeye_dlt (linear/handeye.h, handeyedlt.cpp:126-137): all-pairs Tsai-Lenz seed, pairs enumerated on the GPU."""
+    lib = capi.load_library()
+    n = len(base_se3_gripper)
+    if len(camera_se3_target) != n:
+        raise capi.CbaError(capi.CBA_ERR_RUNTIME, "Inconsistent hand-eye input sizes")
+    bg = np.stack([pose_from_matrix(m) for m in base_se3_gripper]) if n else np.zeros((0, 7))
+    ct = np.stack([pose_from_matrix(m) for m in camera_se3_target]) if n else np.zeros((0, 7))
+    x = np.zeros(7)
+    capi.check(lib, lib.cba_estimate_handeye_dlt(n, dptr(bg), dptr(ct), float(min_angle_deg), dptr(x)))
+    return pose_to_matrix(x)
+
+
+def estimate_and_optimize_handeye(base_se3_gripper, camera_se3_target, min_angle_deg: float = 1.0,
+                                  options: Optional[OptimOptions] = None) -> HandeyeResult:
+    """estimate_and_optimize_handeye (optim/handeye.h:64-67, handeye.cpp:80-87)."""
+    init = estimate_handeye_dlt(base_se3_gripper, camera_se3_target, min_angle_deg)
+    return optimize_handeye(base_se3_gripper, camera_se3_target, init, options)
+
+
 def optimize_planar_pose_batch(views, intrinsics, init_poses, opts: Optional[PlanarPoseOptions] = None) -> List[PlanarPoseResult]:
     """Batched optimize_planar_pose: every view is an independent 6-parameter variable-projection solve, all run
     in ONE kernel launch (one GPU thread per view).  intrinsics = [fx, fy, cx, cy, skew]."""

@@ -252,6 +252,18 @@ cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, c
                                 double* g_T_c /*[7] in/out*/, const cba_options* opts, cba_summary* summary,
                                 double* cov);
 
+/* estimate_handeye_dlt (include/calib/estimation/linear/handeye.h, src/estimation/linear/handeyedlt.cpp:126-137): the all-pairs
+ * Tsai-Lenz seed — rotation from sum skew(alpha+beta) x = beta - alpha, translation from sum (R_A - I) t = R_X t_B - t_A, both
+ * ridge 1e-12 — over the pairs that pass the filter at min_angle_deg (:25-49).  O(n^2) pairs are enumerated on the device.
+ * g_T_c [7] out.  RUNTIME error for < 2 poses / no valid pairs.
+ * estimate_and_optimize_handeye (include/calib/estimation/optim/handeye.h:64-67, handeye.cpp:80-87): that seed, then
+ * cba_optimize_handeye. */
+cba_status cba_estimate_handeye_dlt(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                    double min_angle_deg, double* g_T_c /*[7] out*/);
+cba_status cba_estimate_and_optimize_handeye(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                             double min_angle_deg /*reference default 1.0*/, double* g_T_c /*[7] out*/,
+                                             const cba_options* opts, cba_summary* summary, double* cov);
+
 /* optimize_planar_pose (include/calib/estimation/optim/planarpose.h:24-26, src/estimation/optim/planarpose.cpp:84-127):
  * pose refinement of ONE planar view for fixed K = [fx, fy, cx, cy, skew] by variable projection over the
  * Brown-Conrady coefficients (num_radial radial + 2 tangential, PlanarPoseOptions::num_radial default 2).

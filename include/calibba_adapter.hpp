@@ -10,6 +10,7 @@
 //   calib::optimize_extrinsics<CameraT>                    src/estimation/optim/extrinsics.cpp:174-196
 //   calib::optimize_bundle<CameraT>                        src/estimation/optim/bundle.cpp:147-170
 //   calib::optimize_handeye                                src/estimation/optim/handeye.cpp:60-78
+//   calib::estimate_and_optimize_handeye                   src/estimation/optim/handeye.cpp:80-87
 //   calib::optimize_intrinsics_semidlt                     src/estimation/optim/intrinsicssemidlt.cpp:155-191
 //   calib::optimize_planar_pose                            src/estimation/optim/planarpose.cpp:84-127
 //   calib::optimize_homography                             src/estimation/optim/homography.cpp:144-175
@@ -219,6 +220,24 @@ inline auto optimize_handeye(const std::vector<Eigen::Isometry3d>& base_se3_grip
     cba_options o = make_options(options);
     cba_summary sum{};
     check(cba_optimize_handeye(static_cast<int32_t>(n), bg.data(), ct.data(), x.data(), &o, &sum, cov.data()));
+    calib::HandeyeResult res;
+    res.g_se3_c = pose_out(x.data());
+    fill_core(sum, o, cov, 7, res.core);
+    return res;
+}
+
+// estimate_and_optimize_handeye (handeye.cpp:80-87): the Tsai-Lenz all-pairs seed and the refinement, both on the device
+inline auto estimate_and_optimize_handeye(const std::vector<Eigen::Isometry3d>& base_se3_gripper,
+                                          const std::vector<Eigen::Isometry3d>& camera_se3_target, double min_angle_deg = 1.0,
+                                          const calib::OptimOptions& options = {}) -> calib::HandeyeResult {
+    if (base_se3_gripper.size() < 2 || base_se3_gripper.size() != camera_se3_target.size())  // handeyedlt.cpp:56-58
+        throw std::runtime_error("Inconsistent hand-eye input sizes");
+    const size_t n = base_se3_gripper.size();
+    std::vector<double> bg(7 * n), ct(7 * n), x(7), cov(49);
+    for (size_t i = 0; i < n; ++i) { pose_in(base_se3_gripper[i], &bg[7 * i]); pose_in(camera_se3_target[i], &ct[7 * i]); }
+    cba_options o = make_options(options);
+    cba_summary sum{};
+    check(cba_estimate_and_optimize_handeye(static_cast<int32_t>(n), bg.data(), ct.data(), min_angle_deg, x.data(), &o, &sum, cov.data()));
     calib::HandeyeResult res;
     res.g_se3_c = pose_out(x.data());
     fill_core(sum, o, cov, 7, res.core);

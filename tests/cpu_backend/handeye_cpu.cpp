@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../calibration_amd/csrc/handeye_core.hpp"
+#include "../../calibration_amd/csrc/seed_math.hpp"
 
 using namespace cba;
 
@@ -49,6 +50,29 @@ void hm_axxb_eval(const double* q, const double* t, const double* RA, const doub
     double RX[9];
     quat_to_rotmat(q, RX);
     axxb_point(RX, t, RA, RB, tA, tB, r6, J66);
+}
+
+// Tsai-Lenz all-pairs seed through the product's per-pair sums (axxb_math.hpp), serial; returns 0, 1 (no pairs) or 2 (singular)
+int hm_handeye_dlt(int n, const double* bTg, const double* cTt, double min_angle_deg, double* pose7) {
+    CpuAxxb ev(n, bTg, cTt);
+    const double min_angle = min_angle_deg * 3.14159265358979323846 / 180.0;
+    double w[3], RX[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3];
+    for (int mode = 0; mode < 2; ++mode) {
+        double acc[AXXB_NACC] = {0};
+        for (int i = 0; i + 1 < n; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                const double *pi = &ev.poses[24 * static_cast<size_t>(i)], *pj = &ev.poses[24 * static_cast<size_t>(j)];
+                double RA[9], RB[9], tA[3], tB[3];
+                if (!motion_pair(pi, pi + 9, pj, pj + 9, pi + 12, pi + 21, pj + 12, pj + 21, min_angle, 1e-3, RA, RB, tA, tB)) continue;
+                tsai_lenz_accumulate(mode, RA, RB, tA, tB, RX, acc);
+            }
+        if (acc[9] < 0.5) return 1;
+        if (!tsai_lenz_solve(acc, 1e-12, mode == 0 ? w : t)) return 2;
+        if (mode == 0) exp_so3(w, RX);
+    }
+    seed_rotmat_to_quat(RX, pose7);
+    for (int k = 0; k < 3; ++k) pose7[4 + k] = t[k];
+    return 0;
 }
 
 // number of pairs the product's filter keeps, and the pairs themselves ([RA RB tA tB] x 24) if out != NULL

@@ -89,6 +89,7 @@ def load_hostmath():
     h.hm_axxb_eval.argtypes = [c_double_p] * 8
     h.hm_axxb_eval.restype = None
     h.hm_build_pairs.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p]
+    h.hm_handeye_dlt.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
     h.hm_handeye_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
     return h
 
@@ -232,6 +233,33 @@ def handeye_scene(n_poses=18, seed=2024, noise_rot_deg=0.0, noise_trans=0.0):
     X0[:3, :3] = axis_angle_to_R(rng.rand_unit_axis(), np.deg2rad(2.0)) @ X0[:3, :3]
     X0[:3, 3] += [0.01, -0.005, 0.004]
     return seq, cTt, X, X0
+
+
+def tsai_lenz_dlt(b_T_g, c_T_t, min_angle_deg=1.0):
+    """numpy restatement of estimate_handeye_dlt (src/estimation/linear/handeyedlt.cpp:84-137, se3_utils.h:42-63): the checker
+    for cba_estimate_handeye_dlt.  Raises RuntimeError like the reference when no pair survives the filter."""
+    pairs = build_all_pairs(b_T_g, c_T_t, min_angle_deg)
+    if len(pairs) == 0:
+        raise RuntimeError("No valid motion pairs after filtering. Increase motion or relax thresholds.")
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    M, d = [], []
+    for p in pairs:
+        al, be = log_so3(p[:9].reshape(3, 3)), log_so3(p[9:18].reshape(3, 3))
+        M.append(skew(al + be))
+        d.append(be - al)
+    M, d = np.concatenate(M), np.concatenate(d)
+    w = np.linalg.solve(M.T @ M + 1e-12 * np.eye(3), M.T @ d)
+    th = np.linalg.norm(w)
+    RX = np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) * skew(w / th) + (1 - np.cos(th)) * skew(w / th) @ skew(w / th)
+    Cm = np.concatenate([p[:9].reshape(3, 3) - np.eye(3) for p in pairs])
+    wv = np.concatenate([RX @ p[21:24] - p[18:21] for p in pairs])
+    t = np.linalg.solve(Cm.T @ Cm + 1e-12 * np.eye(3), Cm.T @ wv)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = RX, t
+    return T
 
 
 # ---- planar pose (planarpose_test.cpp:15-34, 96-211) -----------------------------------------------

@@ -562,3 +562,21 @@ def test_planar_seed_batch_on_gpu(gpu_lib):
     assert r.core.success and np.abs(r.camera[:4] - kgt[:4]).max() <= 1e-6 and np.abs(r.distortion - agt).max() <= 1e-7
     with pytest.raises(ValueError, match="out of range"):
         optim.optimize_intrinsics_semidlt(vs, d["kappa0"], None, fixed_distortion_indices=[7])
+
+
+# ---- Tsai-Lenz seed + estimate_and_optimize_handeye on the GPU -------------------------------------------------------------------
+def test_tsai_lenz_seed_and_combined_entry_point_on_gpu(gpu_lib):
+    from calibration_amd.geometry import rotation_angle
+
+    for n, noise in ((20, 0.0), (20, 0.05), (150, 0.05)):
+        bTg, cTt, X, _ = helpers.handeye_scene(n, seed=123, noise_rot_deg=noise, noise_trans=noise * 1e-3)
+        T = optim.estimate_handeye_dlt(bTg, cTt, 1.0)
+        assert np.abs(T - helpers.tsai_lenz_dlt(bTg, cTt, 1.0)).max() <= 1e-10
+        assert np.rad2deg(rotation_angle(T[:3, :3].T @ X[:3, :3])) < 10 and np.linalg.norm(T[:3, 3] - X[:3, 3]) < 0.03  # see test_host_logic
+    with pytest.raises(RuntimeError, match="No valid motion pairs"):
+        optim.estimate_handeye_dlt([np.eye(4)] * 5, [np.eye(4)] * 5, 2.0)
+    # handeye_test.cpp:101-152 through estimate_and_optimize_handeye: 18 frames, Huber 1.0, rot < 0.05 deg, trans < 2 mm
+    bTg, cTt, X, _ = helpers.handeye_scene(18, seed=2024, noise_rot_deg=0.02, noise_trans=2e-4)
+    r = optim.estimate_and_optimize_handeye(bTg, cTt, 1.0, optim.OptimOptions(max_iterations=60, huber_delta=1.0))
+    assert r.core.success
+    assert np.rad2deg(rotation_angle(r.g_se3_c[:3, :3].T @ X[:3, :3])) < 0.05 and np.linalg.norm(r.g_se3_c[:3, 3] - X[:3, 3]) < 2e-3

@@ -568,3 +568,37 @@ def test_semidlt_too_few_observations_is_runtime_error(hostmath):
     st = helpers.semidlt_solve(hostmath.hm_semidlt_solve, d1, 2, options(), want_cov=False)
     assert st[0] != 0 and b"Failed to compute distortion parameters" in hostmath.hm_semidlt_last_error()
     assert st[3].termination == capi.TERM_FAILURE and not st[3].success
+
+
+# ---- Tsai-Lenz all-pairs seed (estimate_handeye_dlt): per-pair sums of the product vs the numpy restatement + reference KATs ----
+def _poses7(Ts):
+    from calibration_amd.geometry import pose_from_matrix
+
+    return np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in Ts]))
+
+
+def test_tsai_lenz_seed_matches_restatement_and_reference_kats(hostmath):
+    from calibration_amd.geometry import inv, make_pose, pose_to_matrix, rotation_angle
+
+    # handeye_test.cpp:13-60: 20 frames, noisy camera poses -> rot < 10 deg, trans < 5 mm; and exactness vs the restatement
+    for noise in (0.0, 0.05):
+        bTg, cTt, X, _ = helpers.handeye_scene(20, seed=123, noise_rot_deg=noise, noise_trans=noise * 1e-3)
+        p = np.zeros(7)
+        assert hostmath.hm_handeye_dlt(len(bTg), dptr(_poses7(bTg)), dptr(_poses7(cTt)), 1.0, dptr(p)) == 0
+        T = pose_to_matrix(p)
+        Tr = helpers.tsai_lenz_dlt(bTg, cTt, 1.0)
+        assert np.abs(T - Tr).max() <= 1e-10
+        # the reference's own bound (rot < 10 deg, trans < 5 mm) holds for ITS random sequence; the estimator is approximate even
+        # on exact data (it solves skew(alpha + beta) x = beta - alpha for a rotation VECTOR), so only a loose bound is asserted here
+        assert np.rad2deg(rotation_angle(T[:3, :3].T @ X[:3, :3])) < 10 and np.linalg.norm(T[:3, 3] - X[:3, 3]) < 0.03
+    # :62-69 all poses identical -> no valid pairs
+    ident = _poses7([np.eye(4)] * 5)
+    assert hostmath.hm_handeye_dlt(5, dptr(ident), dptr(ident), 2.0, dptr(np.zeros(7))) == 1
+    # :71-99 invariance to a left-multiplied base frame: 1e-6 deg, 1e-9 m
+    bTg, cTt, X, _ = helpers.handeye_scene(12, seed=77)
+    B = make_pose([0.5, -0.1, 0.2], np.array([0.3, 0.7, 0.2]) / np.linalg.norm([0.3, 0.7, 0.2]), np.deg2rad(25))
+    p1, p2 = np.zeros(7), np.zeros(7)
+    assert hostmath.hm_handeye_dlt(12, dptr(_poses7(bTg)), dptr(_poses7(cTt)), 1.0, dptr(p1)) == 0
+    assert hostmath.hm_handeye_dlt(12, dptr(_poses7([B @ T for T in bTg])), dptr(_poses7(cTt)), 1.0, dptr(p2)) == 0
+    T1, T2 = pose_to_matrix(p1), pose_to_matrix(p2)
+    assert np.rad2deg(rotation_angle(T1[:3, :3].T @ T2[:3, :3])) < 1e-6 and np.linalg.norm(T1[:3, 3] - T2[:3, 3]) < 1e-9
