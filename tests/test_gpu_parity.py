@@ -580,3 +580,68 @@ def test_tsai_lenz_seed_and_combined_entry_point_on_gpu(gpu_lib):
     r = optim.estimate_and_optimize_handeye(bTg, cTt, 1.0, optim.OptimOptions(max_iterations=60, huber_delta=1.0))
     assert r.core.success
     assert np.rad2deg(rotation_angle(r.g_se3_c[:3, :3].T @ X[:3, :3])) < 0.05 and np.linalg.norm(r.g_se3_c[:3, 3] - X[:3, 3]) < 2e-3
+
+
+def test_full_size_c2_properties(gpu_lib):
+    """BASELINE configs[1] at FULL size (1000 views x 10 000 points = 1e7 observations; the oracle would need minutes): the
+    size-independent properties of the path.  Mode A's J^T r equals Mode B's gradient block by block, Mode B's |r|^2 and the
+    cost kernel agree with 1/2 |r|^2 from Mode A, evaluation is deterministic, and the LM recovers the camera to the
+    statistical accuracy of 0.2 px noise on 1e7 observations."""
+    sc = synth.scene_intrinsics(1000, rows=100, cols=100, spacing=0.008, noise_px=0.2)
+    with optim.ReprojHandle(sc.flat) as h:
+        h.eval()
+        r, J = h.eval_fetch()
+        nb = h.block_normal_eq()
+        assert np.array_equal(nb, h.block_normal_eq())
+        c = h.cost(-1.0)
+        p = J.shape[1]
+        nh = p * (p + 1) // 2
+        off = sc.flat.blk_offset
+        worst_g, worst_h = 0.0, 0.0
+        for b in range(0, sc.flat.n_blocks, 37):  # every 37th block: 28 blocks x 20 000 rows
+            lo, hi = 2 * off[b], 2 * off[b + 1]
+            Jb, rb = J[lo:hi], r[lo:hi]
+            g = Jb.T @ rb
+            worst_g = max(worst_g, np.abs(g - nb[b, nh:nh + p]).max() / max(1.0, np.abs(g).max()))
+            H = Jb.T @ Jb
+            worst_h = max(worst_h, np.abs(H[np.triu_indices(p)] - nb[b, :nh]).max() / np.abs(H).max())
+        assert worst_g <= 1e-9 and worst_h <= 1e-10
+        assert abs(nb[:, -1].sum() - float(r @ r)) <= 1e-10 * float(r @ r)
+        assert abs(c - 0.5 * float(r @ r)) <= 1e-10 * c
+        del r, J
+        o = options(compute_covariance=0)
+        s = h.solve(o)
+        assert s.success and s.iterations <= 15
+        cs = h.covariance_shared(o)
+    err = np.abs(sc.flat.intr - sc.gt_intr).reshape(-1)
+    sig = np.sqrt(np.diag(cs))
+    act = sig > 0
+    assert (err[act] <= 6.0 * sig[act]).all(), (err, sig)  # within 6 sigma of the engine's own covariance
+    assert err[:4].max() < 0.2  # and well under a fifth of a pixel in fx, fy, cx, cy
+
+
+def test_c3_shaped_moment_mode_b_equals_direct_mode_b(gpu_lib, monkeypatch):
+    """BASELINE configs[2] shape at 1/20 of the views (200 views x 8 cameras x 5000 points = 8e6 observations): the moment
+    form of Mode B (k_normal_eq_mom + k_mom_expand) against the direct 22-column form, block by block, and the LM end result."""
+    def run(moments):
+        monkeypatch.setenv("CBA_MODEB_MOMENTS", str(moments))
+        sc = synth.scene_extrinsics(200, 8, rows=50, cols=100, spacing=0.008, noise_px=0.2, seed=137)
+        with optim.ReprojHandle(sc.flat) as h:
+            nb = h.block_normal_eq()
+            s = h.solve(options(compute_covariance=0))
+        return sc, nb, s
+
+    sa, na, ra = run(1)
+    sb, nb_, rb = run(0)
+    p = helpers.local_cols(sa.flat)
+    nh = p * (p + 1) // 2
+    diag = np.sqrt(na[:, [i * p - i * (i - 1) // 2 for i in range(p)]])  # sqrt(H_ii) per block
+    iu = np.triu_indices(p)
+    scale = diag[:, iu[0]] * diag[:, iu[1]]
+    ok = scale > 0
+    assert (np.abs(na[:, :nh] - nb_[:, :nh])[ok] / scale[ok]).max() <= 1e-10
+    assert np.abs(na[:, nh:] - nb_[:, nh:]).max() <= 1e-9 * np.abs(nb_[:, nh:]).max()
+    assert ra.success and rb.success and ra.iterations == rb.iterations
+    assert abs(ra.final_cost - rb.final_cost) <= 1e-10 * rb.final_cost
+    assert helpers.param_diff(sa.flat, sb.flat) <= 1e-9
+    assert np.abs(sa.flat.intr - sa.gt_intr)[:, :4].max() < 0.5
