@@ -564,12 +564,15 @@ void engine_allreduce(Engine& e, double* buf, int64_t n) {
     if (n <= 0) return;
     if (e.rccl_comm) {
         if (e.coll_buf.n < static_cast<size_t>(n)) e.coll_buf.alloc(static_cast<size_t>(n) * 2);
-        e.coll_buf.upload(buf, static_cast<size_t>(n), e.stream);
+        e.coll_pin.reserve(static_cast<size_t>(n) * 2);
+        std::memcpy(e.coll_pin.p, buf, sizeof(double) * static_cast<size_t>(n));
+        e.coll_buf.upload(e.coll_pin.p, static_cast<size_t>(n), e.stream);
         const ncclResult_t r = ncclAllReduce(e.coll_buf.p, e.coll_buf.p, static_cast<size_t>(n), ncclDouble, ncclSum,
                                              reinterpret_cast<ncclComm_t>(e.rccl_comm), e.stream);
         if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-        e.coll_buf.download(buf, static_cast<size_t>(n), e.stream);
+        e.coll_buf.download(e.coll_pin.p, static_cast<size_t>(n), e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
+        std::memcpy(buf, e.coll_pin.p, sizeof(double) * static_cast<size_t>(n));
     } else if (e.allreduce) {
         if (e.allreduce(buf, n, e.allreduce_user) != 0) throw std::runtime_error("allreduce callback failed");
     }

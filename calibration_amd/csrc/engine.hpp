@@ -172,6 +172,7 @@ struct Engine {
     void* rccl_comm = nullptr;
     int n_ranks = 1, rank = 0;
     DevBuf<double> coll_buf;
+    PinnedBuf<double> coll_pin;  // page-locked staging of the packed all-reduce buffer (both copies are queued, one sync)
     void* lm_state = nullptr;  // HipLMState (backend_hip.hip)
 
     ~Engine();

@@ -53,5 +53,27 @@ def main():
                       "mean_iterations": float(np.mean([r.core.iterations for r in res]))}))
 
 
+    # batched DLT seed of the same views
+    for rep in range(2):
+        t0 = time.perf_counter()
+        seeds = optim.estimate_planar_pose_batch(views, cam[:5])
+        t_s = time.perf_counter() - t0
+    err = max(np.abs(S - T).max() for S, T in zip(seeds[:200], poses[:200]))
+    print(json.dumps({"case": "estimate_planar_pose_batch", "views": args.views, "points_per_view": n_pts, "wall_s": t_s,
+                      "views_per_s": args.views / t_s, "max_abs_err_vs_gt_first_200": float(err)}))
+    # semi-DLT intrinsics: 400 views x 30x30 points, seeded on the device, distortion eliminated by variable projection
+    from tests import helpers
+    d, kgt, agt = helpers.semidlt_scene(400, rows=30, cols=30, noise=0.2, nr=2, seed=5)
+    vs = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][:-1], d["off"][1:])]
+    opt = optim.IntrinsicsOptimOptions(core=optim.OptimOptions(compute_covariance=False), num_radial=2)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = optim.optimize_intrinsics_semidlt(vs, d["kappa0"], None, opt)
+        t_sd = time.perf_counter() - t0
+    print(json.dumps({"case": "optimize_intrinsics_semidlt (device seeds)", "views": 400, "points_per_view": 900, "wall_s": t_sd,
+                      "solve_s": r.core.solve_seconds, "iterations": r.core.iterations, "success": r.core.success,
+                      "K_err_px": float(np.abs(r.camera[:4] - kgt[:4]).max()), "alpha_err": float(np.abs(r.distortion - agt).max())}))
+
+
 if __name__ == "__main__":
     main()
