@@ -53,8 +53,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal on a box with fewer GPUs than ranks (CBA_BENCH_BACKEND=gloo): ranks share devices and talk over gloo
+        backend = os.environ.get("CBA_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from calibration_amd import capi, optim, synth
 
@@ -87,7 +93,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * n_obs * args.steps / elapsed
@@ -116,7 +122,12 @@ def main():
     def run_lm():
         try:
             torch.cuda.set_device(local_rank)
-            if world > 1:
+            if world > 1 and dist.get_backend() != "nccl":  # rehearsal: host-callback transport over the CPU backend
+                def _allreduce(arr):
+                    dist.all_reduce(torch.from_numpy(arr))
+                h.set_allreduce(_allreduce, world, rank)
+                transport = f"host callback over torch.distributed {dist.get_backend()} (rehearsal)"
+            elif world > 1:
                 try:  # RCCL-native: ncclAllReduce of the packed reduced system on the engine's stream
                     uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
                     if rank == 0:
