@@ -114,6 +114,15 @@ def main():
                 "traffic_bytes_per_launch": traffic_bytes, "algorithmic_bytes_per_launch": bytes_per_obs * n_obs,
                 "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
+    # ---- Mode B (per-block normal equations, the kernel that sets the LM wall clock): fp64-issue bound ----------------
+    # operations per observation counted from the kernel source: 225 fused accumulate operations for the
+    # whole [H | g | s] row + 2 launches x ~110 for the residual / Jacobian rows; FMA = 2 FLOP, vector fp64 peak 78.6 TFLOP/s
+    ms_b = h.normal_eq_timed(2, 10)
+    ops_b = 225 + 2 * 110
+    mode_b = {"kernel": "k_normal_eq<INTRINSIC,PINHOLE_BC> x2 + k_tile_sum", "ms_per_pass": ms_b, "bound": "fp64 vector issue",
+              "fp64_ops_per_obs": ops_b, "achieved_TFLOPs": 2 * ops_b * n_obs / (ms_b * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
+              "frac": 2 * ops_b * n_obs / (ms_b * 1e-3) / 78.6e12, "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
+
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path
     # cannot be rehearsed on a 1-GPU box) must not swallow the evals/s line measured above.
@@ -210,6 +219,7 @@ def main():
                        "parallelism": f"views sharded over {world} GPU(s)"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "mode_b": mode_b,
             "lm": lm,
             "scene_gen_s": t_gen,
         }

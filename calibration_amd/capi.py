@@ -143,6 +143,7 @@ PROTOTYPES = {
     "cba_reproj_eval": (C.c_int32, [C.c_void_p]),
     "cba_reproj_eval_fetch": (C.c_int32, [C.c_void_p, c_double_p, c_double_p]),
     "cba_reproj_eval_timed": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
+    "cba_reproj_normal_eq_timed": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
     "cba_reproj_set_scalar": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cba_reproj_eval_fetch_f32": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cba_reproj_cost": (C.c_int32, [C.c_void_p, C.c_double, c_double_p]),

@@ -382,6 +382,23 @@ cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, d
     });
 }
 
+cba_status cba_reproj_normal_eq_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_pass) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (iters <= 0) throw std::invalid_argument("iters must be positive");
+        CBA_HIP(hipSetDevice(e.device));
+        launch_block_consts(e, 0);
+        for (int i = 0; i < warmup; ++i) launch_normal_eq(e);
+        CBA_HIP(hipEventRecord(e.ev0, e.stream));
+        for (int i = 0; i < iters; ++i) launch_normal_eq(e);
+        CBA_HIP(hipEventRecord(e.ev1, e.stream));
+        CBA_HIP(hipEventSynchronize(e.ev1));
+        float ms = 0.f;
+        CBA_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
+        *ms_per_pass = static_cast<double>(ms) / iters;
+    });
+}
+
 cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
     return guarded([&] {
         Engine& e = *as_engine(h);

@@ -358,6 +358,12 @@ class ReprojHandle:
         capi.check(self.lib, self.lib.cba_reproj_eval_timed(self.h, int(warmup), int(iters), C.byref(ms)))
         return float(ms.value)
 
+    def normal_eq_timed(self, warmup: int, iters: int) -> float:
+        """Average milliseconds of one Mode B pass (per-block normal equations), HIP events on the engine's stream."""
+        ms = C.c_double()
+        capi.check(self.lib, self.lib.cba_reproj_normal_eq_timed(self.h, int(warmup), int(iters), C.byref(ms)))
+        return ms.value
+
     def cost(self, huber_delta: float = 1.0) -> float:
         c = C.c_double(0.0)
         capi.check(self.lib, self.lib.cba_reproj_cost(self.h, float(huber_delta), C.byref(c)))

@@ -180,6 +180,9 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J);
  * returns the average milliseconds per evaluation of the dominant kernel region. */
 cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_eval);
 
+/* The same for one Mode B pass (all launches that produce the per-block normal equations of a linearisation). */
+cba_status cba_reproj_normal_eq_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_pass);
+
 /* Arithmetic type of the per-observation kernels (BASELINE config 5's fp32-vs-fp64 study): 0 = fp64
  * (default), 1 = fp32: observations and per-block constants are rounded to fp32 once, the residual and
  * Jacobian rows are evaluated in fp32, and EVERY accumulator (J^T J, J^T r, |r|^2), the Schur step and the
