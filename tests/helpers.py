@@ -9,8 +9,9 @@ from calibration_amd import capi
 from calibration_amd.capi import CbaOptions, CbaReprojProblem, CbaSummary, c_double_p, dptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-HOSTMATH_SO = os.path.join(ROOT, "tests", "cpu_backend", "_build", "libhostmath.so")
+# CBA_TEST_LIBDIR: alternative builds of the two test-only libraries (e.g. -fsanitize=address,undefined builds under /tmp)
+ORACLE_SO = os.path.join(os.environ.get("CBA_TEST_LIBDIR", os.path.join(ROOT, "oracle", "_build")), "liboracle.so")
+HOSTMATH_SO = os.path.join(os.environ.get("CBA_TEST_LIBDIR", os.path.join(ROOT, "tests", "cpu_backend", "_build")), "libhostmath.so")
 
 PP = C.POINTER(CbaReprojProblem)
 PO = C.POINTER(CbaOptions)
