@@ -645,3 +645,33 @@ def test_c3_shaped_moment_mode_b_equals_direct_mode_b(gpu_lib, monkeypatch):
     assert abs(ra.final_cost - rb.final_cost) <= 1e-10 * rb.final_cost
     assert helpers.param_diff(sa.flat, sb.flat) <= 1e-9
     assert np.abs(sa.flat.intr - sa.gt_intr)[:, :4].max() < 0.5
+
+
+@pytest.mark.parametrize("chain", ["intr", "ext"])
+def test_mode_b_tile_boundaries(gpu_lib, oracle, chain):
+    """Mode B / Mode R tile edges (a tile is 64 lanes x 16 passes = 1024 observations; the loads of pass k+1 are prefetched):
+    blocks of 63, 64, 65, 1023, 1024, 1025, 2049 and 3000 points, for the direct form (INTRINSIC chain) and the moment
+    form (EXTRINSIC chain), against the oracle's Jets."""
+    sizes = [63, 64, 65, 1023, 1024, 1025, 2049, 3000]
+    if chain == "intr":
+        sc = synth.scene_intrinsics(len(sizes), rows=55, cols=55, spacing=0.012, noise_px=0.3)
+        f = sc.flat
+        views = [np.stack([f.X[f.blk_offset[b]:f.blk_offset[b] + n], f.Y[f.blk_offset[b]:f.blk_offset[b] + n],
+                           f.u[f.blk_offset[b]:f.blk_offset[b] + n], f.v[f.blk_offset[b]:f.blk_offset[b] + n]], axis=1)
+                 for b, n in enumerate(sizes)]
+        flat = optim.FlatProblem(f.chain, f.model, views, np.zeros(len(sizes), np.int32), np.arange(len(sizes), dtype=np.int32),
+                                 f.intr, None, f.view_pose, None)
+    else:
+        sc = synth.scene_extrinsics(4, 2, rows=55, cols=55, spacing=0.012, noise_px=0.3)
+        f = sc.flat
+        views = [np.stack([f.X[f.blk_offset[b]:f.blk_offset[b] + n], f.Y[f.blk_offset[b]:f.blk_offset[b] + n],
+                           f.u[f.blk_offset[b]:f.blk_offset[b] + n], f.v[f.blk_offset[b]:f.blk_offset[b] + n]], axis=1)
+                 for b, n in enumerate(sizes)]
+        flat = optim.FlatProblem(f.chain, f.model, views, f.blk_cam, f.blk_view, f.intr, f.cam_pose, f.view_pose, None)
+    flat.intr[...] = flat.intr * (1 + 0.01 * np.random.default_rng(5).uniform(-1, 1, flat.intr.shape))
+    with optim.ReprojHandle(flat) as h:
+        nb = h.block_normal_eq()
+        c1 = h.cost(1.0)
+    ref = helpers.oracle_block_normal_eq(oracle, flat)
+    assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
+    assert abs(c1 - helpers.oracle_cost(oracle, flat)) <= 1e-10 * max(1.0, c1)
