@@ -675,3 +675,23 @@ def test_mode_b_tile_boundaries(gpu_lib, oracle, chain):
     ref = helpers.oracle_block_normal_eq(oracle, flat)
     assert (np.abs(nb - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-10
     assert abs(c1 - helpers.oracle_cost(oracle, flat)) <= 1e-10 * max(1.0, c1)
+
+
+from tests.test_host_logic import _sweep_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("idx,kind,seed,noise,okw", _sweep_cases(18, seed=77))
+def test_random_option_sweep_on_gpu(gpu_lib, oracle, idx, kind, seed, noise, okw):
+    """The stage-switch sweep of tests/test_host_logic.py through the HIP engine: same constant blocks, gauge rules and end point."""
+    mk = {"intr": lambda: synth.scene_intrinsics(6, spacing=0.08, noise_px=noise, seed=seed),
+          "ext": lambda: synth.scene_extrinsics(4, 3, spacing=0.08, noise_px=noise, seed=seed),
+          "bundle": lambda: synth.scene_bundle(8, 2, spacing=0.04, noise_px=noise, seed=seed)}[kind]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **okw)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+    assert sb.termination == sa.termination, (sa.report, sb.report)
+    assert abs(sb.iterations - sa.iterations) <= 2
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
+    assert helpers.param_diff(a.flat, b.flat) <= (5e-8 if okw.get("optimize_skew") else 2e-9), okw

@@ -602,3 +602,37 @@ def test_tsai_lenz_seed_matches_restatement_and_reference_kats(hostmath):
     assert hostmath.hm_handeye_dlt(12, dptr(_poses7([B @ T for T in bTg])), dptr(_poses7(cTt)), 1.0, dptr(p2)) == 0
     T1, T2 = pose_to_matrix(p1), pose_to_matrix(p2)
     assert np.rad2deg(rotation_angle(T1[:3, :3].T @ T2[:3, :3])) < 1e-6 and np.linalg.norm(T1[:3, 3] - T2[:3, 3]) < 1e-9
+
+
+# ---- randomised option sweep: the product's host LM (Schur-reduced, masks, gauge) vs the oracle's dense LM ---------------------
+def _sweep_cases(n=24, seed=2026):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        kind = ["intr", "ext", "bundle"][i % 3]
+        okw = dict(huber_delta=float(rng.choice([1.0, -1.0, 0.5])), optimize_skew=int(rng.integers(0, 2)))
+        if kind != "intr":
+            okw.update(optimize_intrinsics=int(rng.integers(0, 2)), optimize_extrinsics=int(rng.integers(0, 2)))
+        if kind == "bundle":
+            okw.update(optimize_target_pose=int(rng.integers(0, 2)))
+        cases.append((i, kind, int(rng.integers(100, 10_000)), float(rng.choice([0.0, 0.2])), okw))
+    return cases
+
+
+@pytest.mark.parametrize("idx,kind,seed,noise,okw", _sweep_cases())
+def test_random_option_sweep_matches_oracle(oracle, hostmath, idx, kind, seed, noise, okw):
+    """Every combination of the stage switches (optimize_intrinsics / skew / extrinsics / hand-eye / target pose, loss on/off)
+    decides which blocks Ceres holds constant and which gauge rule applies (extrinsics.cpp:118-140, bundle.cpp:103-131): the
+    Schur-reduced product driver and the dense oracle must take the same decisions and land on the same parameters."""
+    mk = {"intr": lambda: synth.scene_intrinsics(6, spacing=0.08, noise_px=noise, seed=seed),
+          "ext": lambda: synth.scene_extrinsics(4, 3, spacing=0.08, noise_px=noise, seed=seed),
+          "bundle": lambda: synth.scene_bundle(8, 2, spacing=0.04, noise_px=noise, seed=seed)}[kind]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **okw)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sb.termination == sa.termination, (sa.report, sb.report)
+    assert abs(sb.iterations - sa.iterations) <= 2
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
+    tol = 5e-8 if okw.get("optimize_skew") else 2e-9
+    assert helpers.param_diff(a.flat, b.flat) <= tol, (okw, helpers.param_diff(a.flat, b.flat))
