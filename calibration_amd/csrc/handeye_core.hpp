@@ -41,13 +41,16 @@ inline void handeye_lm(AxxbEval& ev, double* pose7, const cba_options& o, cba_su
         throw std::runtime_error("No valid motion pairs after filtering. Increase motion or relax thresholds.");
     double cost = acc[27];
     const double initial_cost = cost;
+    bool finite0 = std::isfinite(cost);
+    for (int e = 0; e < 27; ++e) finite0 = finite0 && std::isfinite(acc[e]);
     axxb_unpack(acc, H, g);
     for (int i = 0; i < 6; ++i) { const double s = 1.0 / (1.0 + std::sqrt(H[i * 6 + i])); scale2[i] = s * s; }
     auto gmax_of = [&]() { double m = 0; for (int i = 0; i < 6; ++i) m = std::max(m, std::fabs(g[i])); return m; };
     double gmax = gmax_of(), radius = 1e4, decrease_factor = 2.0;
     int iter = 0, invalid = 0, successful = 0, term = CBA_TERM_FAILURE;
     const char* msg = "";
-    if (gmax <= eps) { term = CBA_TERM_CONVERGENCE; msg = "Gradient tolerance reached."; }
+    if (!finite0) { term = CBA_TERM_FAILURE; msg = "Residual and Jacobian evaluation failed (non-finite values)."; }
+    else if (gmax <= eps) { term = CBA_TERM_CONVERGENCE; msg = "Gradient tolerance reached."; }
     else while (true) {
         if (iter >= o.max_iterations) { term = CBA_TERM_NO_CONVERGENCE; msg = "Maximum number of iterations reached."; break; }
         if (gmax <= eps) { term = CBA_TERM_CONVERGENCE; msg = "Gradient tolerance reached."; break; }

@@ -97,6 +97,11 @@ CBA_HD void small_lm_solve(const Problem& P, Coop& co, double eps, int max_itera
     st.cost = st.initial_cost = 0.0;
     st.evaluated = 0;
     if (!P.evaluate(co, st.x, true, &st.cost, st.H, st.g, &aux)) return;  // evaluation failure at x0: Ceres reports FAILURE
+    {   // non-finite cost or gradient at x0 (NaN / Inf observations): Ceres rejects the initial evaluation -> FAILURE
+        bool finite = st.cost == st.cost && fabs(st.cost) <= 1.7976931348623157e308;
+        for (int i = 0; i < NP; ++i) finite = finite && st.g[i] == st.g[i] && fabs(st.g[i]) <= 1.7976931348623157e308;
+        if (!finite) return;
+    }
     st.evaluated = 1;
     st.initial_cost = st.cost;
     for (int i = 0; i < NP; ++i) { const double sc = 1.0 / (1.0 + sqrt(st.H[i * NP + i])); scale2[i] = sc * sc; }

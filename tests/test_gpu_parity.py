@@ -695,3 +695,28 @@ def test_random_option_sweep_on_gpu(gpu_lib, oracle, idx, kind, seed, noise, okw
     assert abs(sb.iterations - sa.iterations) <= 2
     assert abs(sb.final_cost - sa.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
     assert helpers.param_diff(a.flat, b.flat) <= (5e-8 if okw.get("optimize_skew") else 2e-9), okw
+
+
+def test_non_finite_observations_fail_cleanly(gpu_lib):
+    """A NaN pixel must end in termination FAILURE / success = false (as ceres::Solve would report), never in a hang or a
+    crash — for the host-driven LM and for the in-kernel per-view solvers (whose loops are bounded by max_iterations)."""
+    sc = synth.scene_extrinsics(4, 2, noise_px=0.1)
+    sc.flat.u[5] = np.nan
+    with optim.ReprojHandle(sc.flat) as h:
+        s = h.solve(options())
+    assert not s.success and s.termination == capi.TERM_FAILURE and s.iterations <= 5
+    view, H = helpers.homography_scene(50, 0.1)
+    bad = view.copy()
+    bad[7, 2] = np.inf
+    r = optim.optimize_homography_batch([view, bad], [helpers.dlt_homography(view)] * 2)
+    assert r[0].core.success and not r[1].core.success
+    pv, true, init = helpers.planar_pose_scene(distort=True, noise=0.1)
+    badp = pv.copy()
+    badp[3, 3] = np.nan
+    rp = optim.optimize_planar_pose_batch([pv, badp], helpers.PLANAR_K, [init, init])
+    assert rp[0].core.success and not rp[1].core.success
+    bTg, cTt, X, X0 = helpers.handeye_scene(10)
+    cTt[3] = cTt[3].copy()
+    cTt[3][0, 3] = np.nan
+    rh = optim.optimize_handeye(bTg, cTt, X0)
+    assert not rh.core.success

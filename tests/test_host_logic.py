@@ -636,3 +636,21 @@ def test_random_option_sweep_matches_oracle(oracle, hostmath, idx, kind, seed, n
     assert abs(sb.final_cost - sa.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
     tol = 5e-8 if okw.get("optimize_skew") else 2e-9
     assert helpers.param_diff(a.flat, b.flat) <= tol, (okw, helpers.param_diff(a.flat, b.flat))
+
+
+def test_non_finite_observations_fail_cleanly_host_build(hostmath):
+    """NaN / Inf observations: termination FAILURE, success = false (Ceres rejects a non-finite initial evaluation) — the
+    small in-kernel solver must not mistake a NaN gradient for a vanished one."""
+    view, H = helpers.homography_scene(30, 0.1)
+    view[4, 3] = np.nan
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    h, s = helpers.dlt_homography(view[:4]).reshape(9).copy(), CbaSummary()
+    assert hostmath.hm_homography_solve(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(h), C.byref(options()), C.byref(s), dptr(None)) == 0
+    assert not s.success and s.termination == capi.TERM_FAILURE
+    pv, true, init = helpers.planar_pose_scene(distort=True, noise=0.1)
+    pv[2, 2] = np.inf
+    X, Y, u, v = (np.ascontiguousarray(pv[:, k]) for k in range(4))
+    p, s, d, rms = helpers.pose6_of(init), CbaSummary(), np.zeros(4), C.c_double()
+    assert hostmath.hm_planar_pose_solve(len(pv), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(helpers.PLANAR_K), 2, dptr(p), C.byref(options()),
+                                         C.byref(s), dptr(d), C.byref(rms), dptr(None)) == 0
+    assert not s.success and s.termination == capi.TERM_FAILURE
