@@ -248,10 +248,14 @@ class LMDriver {
                 for (int i = 0; i < 6; ++i)
                     cmax = std::max(cmax, std::sqrt(w[s_.link_blk[k]] * acc[static_cast<size_t>(s_.link_blk[k]) * NACC + hidx(PL, i, i)]));
         const double rank_tol = 20.0 * static_cast<double>(2 * s_.n_obs + n + 6 * s_.n_views) * 2.220446049250313e-16 * cmax;
-        // compact active shared indices
+        // compact active shared indices; a non-constant column nobody observes is an all-zero Jacobian column:
+        // ceres::Covariance::Compute fails on it (rank deficient) and the reference leaves the matrix empty
         std::vector<int> act;
         for (int i = 0; i < n; ++i)
-            if (active_[i] && Hcc[static_cast<size_t>(i) * n + i] != 0.0) act.push_back(i);
+            if (active_[i]) {
+                if (Hcc[static_cast<size_t>(i) * n + i] == 0.0) throw std::runtime_error("covariance: rank deficient Jacobian (unobserved parameter)");
+                act.push_back(i);
+            }
         const int na = static_cast<int>(act.size());
         std::vector<int> free_views;
         for (int v = 0; v < s_.n_views; ++v)

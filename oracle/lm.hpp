@@ -438,6 +438,13 @@ class Problem {
     // J^T J is rank deficient (ceres::Covariance::Compute fails => nullopt).
     bool covariance(const LMOptions& o, const std::vector<int>& order, std::vector<double>* cov, int* dim) {
         finalize_layout();
+        {   // ceres::Covariance keeps every NON-CONSTANT parameter block it is asked about: one that no residual block
+            // uses contributes all-zero Jacobian columns, i.e. a rank-deficient Jacobian, and Compute() fails.
+            std::vector<char> used(params.size(), 0);
+            for (auto& rb : residuals) for (int id : rb->pb) used[id] = 1;
+            for (int id : order)
+                if (!params[id].constant && !used[id]) return false;
+        }
         std::vector<double> x, H, g;
         gather(x);
         double cost;

@@ -720,3 +720,28 @@ def test_non_finite_observations_fail_cleanly(gpu_lib):
     cTt[3][0, 3] = np.nan
     rh = optim.optimize_handeye(bTg, cTt, X0)
     assert not rh.core.success
+
+
+def test_unobserved_camera_on_gpu(gpu_lib, oracle):
+    """tests/test_host_logic.py::test_camera_without_observations_and_ragged_rig through the HIP engine: the solve leaves the idle
+    camera untouched and agrees with the oracle; the covariance is reported rank deficient (empty), as ceres::Covariance would."""
+    def make():
+        sc = synth.scene_extrinsics(5, 3, spacing=0.08, noise_px=0.2)
+        f = sc.flat
+        keep = [b for b in range(f.n_blocks) if f.blk_cam[b] != 2 and not (f.blk_cam[b] == 1 and f.blk_view[b] in (0, 2))]
+        views = [np.stack([f.X[f.blk_offset[b]:f.blk_offset[b + 1]], f.Y[f.blk_offset[b]:f.blk_offset[b + 1]],
+                           f.u[f.blk_offset[b]:f.blk_offset[b + 1]], f.v[f.blk_offset[b]:f.blk_offset[b + 1]]], axis=1) for b in keep]
+        return optim.FlatProblem(f.chain, f.model, views, f.blk_cam[keep], f.blk_view[keep], f.intr, f.cam_pose, f.view_pose, None)
+
+    a, b = make(), make()
+    idle = (b.intr[2].copy(), b.cam_pose[2].copy())
+    o = options(epsilon=1e-12)
+    sa = helpers.oracle_solve(oracle, a, o)
+    with optim.ReprojHandle(b) as h:
+        sb = h.solve(o)
+        cov = h.covariance(o)
+        o2 = options(epsilon=1e-12, optimize_intrinsics=0, optimize_extrinsics=0)
+        cov2 = h.covariance(o2)
+    assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and helpers.param_diff(a, b) <= 2e-9
+    assert np.array_equal(b.intr[2], idle[0]) and np.array_equal(b.cam_pose[2], idle[1])
+    assert cov is None and cov2 is not None

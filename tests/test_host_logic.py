@@ -654,3 +654,41 @@ def test_non_finite_observations_fail_cleanly_host_build(hostmath):
     assert hostmath.hm_planar_pose_solve(len(pv), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(helpers.PLANAR_K), 2, dptr(p), C.byref(options()),
                                          C.byref(s), dptr(d), C.byref(rms), dptr(None)) == 0
     assert not s.success and s.termination == capi.TERM_FAILURE
+
+
+def test_camera_without_observations_and_ragged_rig(oracle, hostmath):
+    """extrinsics.cpp:91-106 adds a residual block only for (view, camera) pairs with points: a camera nobody observes has no
+    residual, Ceres drops its parameter blocks from the program (they come back unchanged) and the covariance keeps zero
+    rows for them.  Also a ragged rig: camera 1 misses views 0 and 2."""
+    def make():
+        sc = synth.scene_extrinsics(5, 3, spacing=0.08, noise_px=0.2)
+        f = sc.flat
+        keep = [b for b in range(f.n_blocks) if f.blk_cam[b] != 2 and not (f.blk_cam[b] == 1 and f.blk_view[b] in (0, 2))]
+        views = [np.stack([f.X[f.blk_offset[b]:f.blk_offset[b + 1]], f.Y[f.blk_offset[b]:f.blk_offset[b + 1]],
+                           f.u[f.blk_offset[b]:f.blk_offset[b + 1]], f.v[f.blk_offset[b]:f.blk_offset[b + 1]]], axis=1) for b in keep]
+        return optim.FlatProblem(f.chain, f.model, views, f.blk_cam[keep], f.blk_view[keep], f.intr, f.cam_pose, f.view_pose, None)
+
+    a, b = make(), make()
+    cam2_before = (a.intr[2].copy(), a.cam_pose[2].copy())
+    o = options(epsilon=1e-12)
+    sa = helpers.oracle_solve(oracle, a, o)
+    sb = hm_solve(hostmath, b, o)
+    assert sa.termination == sb.termination == capi.TERM_CONVERGENCE
+    assert helpers.param_diff(a, b) <= 2e-9
+    assert np.array_equal(b.intr[2], cam2_before[0]) and np.array_equal(b.cam_pose[2], cam2_before[1])
+    # covariance: the unobserved camera's blocks are NON-constant with all-zero Jacobian columns -> ceres::Covariance::Compute
+    # fails (rank deficient) and the reference leaves the matrix empty; both the oracle and the product report exactly that
+    assert helpers.oracle_covariance(oracle, a, o) is None
+    d = b.struct()
+    n = int(hostmath.hm_reproj_covariance_dim(C.byref(d)))
+    cov1 = np.zeros((n, n))
+    assert hostmath.hm_reproj_covariance(C.byref(d), C.byref(o), dptr(cov1)) == capi.CBA_ERR_RUNTIME
+    assert b"rank deficient" in hostmath.hm_last_error()
+    # with the idle camera's blocks held constant by the options the matrix exists again and agrees
+    o2 = options(epsilon=1e-12, optimize_intrinsics=0, optimize_extrinsics=0)
+    cov0 = helpers.oracle_covariance(oracle, a, o2)
+    assert hostmath.hm_reproj_covariance(C.byref(d), C.byref(o2), dptr(cov1)) == 0, hostmath.hm_last_error()
+    d0 = np.abs(np.diag(cov0))
+    assert np.array_equal(d0 == 0, np.diag(cov1) == 0)
+    nz = d0 > 0
+    assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-5
