@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_cost(int n_blocks, const double* __rest
     sh[1][threadIdx.x] = ss;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
+        if (static_cast<int>(threadIdx.x) < o) {
             sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         }
