@@ -306,3 +306,37 @@ def test_reference_kat_homography_insufficient_points(oracle):
     view = np.array([[0, 0, 10, 0], [1, 0, 11, 0], [0, 1, 10, 1]], float)
     st, _, _, _ = _oracle_homography(oracle, view, np.eye(3))
     assert st != 0 and b"At least 4" in oracle.orc_last_error()
+
+
+# ---- (2b) golden vectors of the small-solver functors: complex-step THROUGH the least-squares solve (gen_golden_vp.py) ------------
+def test_oracle_vp_functors_match_complex_step_golden(oracle, hostmath):
+    G = _load("vp_jacobians.json")
+    i64 = lambda a: a.ctypes.data_as(helpers.c_int64_p)  # noqa: E731
+    rel = lambda A, B: (np.abs(A - B) / np.maximum(1.0, np.abs(B))).max()  # noqa: E731
+    for c in G["planar_pose"]:
+        X, Y, u, v, K, p = (np.ascontiguousarray(c[k], dtype=float) for k in ("X", "Y", "u", "v", "K", "pose6"))
+        n, m = len(X), c["nr"] + 2
+        r, J, al = np.zeros(2 * n), np.zeros((2 * n, 6)), np.zeros(m)
+        assert oracle.orc_planar_vp_eval(n, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), c["nr"], dptr(p), dptr(r), dptr(J), dptr(al)) == 0
+        assert np.abs(r - np.array(c["r"])).max() <= 1e-9 and rel(J, np.array(c["J"])) <= 1e-9 and rel(al, np.array(c["alpha"])) <= 1e-9
+        # the product's analytic Golub-Pereyra rows (host build of vp_math.hpp) against the same independent vectors
+        r1, J1, a1, H, g = np.zeros(2 * n), np.zeros((2 * n, 6)), np.zeros(m), np.zeros((6, 6)), np.zeros(6)
+        assert hostmath.hm_planar_vp_eval(n, dptr(X), dptr(Y), dptr(u), dptr(v), dptr(K), c["nr"], dptr(p), dptr(r1), dptr(J1), dptr(a1), dptr(H),
+                                          dptr(g)) == 0
+        assert np.abs(r1 - np.array(c["r"])).max() <= 1e-9 and rel(J1, np.array(c["J"])) <= 1e-9
+    for c in G["semidlt"]:
+        V = c["n_views"]
+        views = [tuple(np.asarray(a, dtype=float) for a in vw) for vw in c["views"]]
+        off = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum([len(vw[0]) for vw in views], out=off[1:])
+        X, Y, u, v = (np.ascontiguousarray(np.concatenate([vw[k] for vw in views])) for k in range(4))
+        kap, pos = np.ascontiguousarray(c["kappa"], dtype=float), np.ascontiguousarray(c["poses7"], dtype=float)
+        N = int(off[-1])
+        r, J, al = np.zeros(2 * N), np.zeros((2 * N, 5 + 7 * V)), np.zeros(c["nr"] + 2)
+        assert oracle.orc_semidlt_eval(V, i64(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(kap), dptr(pos), c["nr"], dptr(r), dptr(J), dptr(al)) == 0
+        assert np.abs(r - np.array(c["r"])).max() <= 1e-9 and rel(J, np.array(c["J"])) <= 1e-8 and rel(al, np.array(c["alpha"])) <= 1e-9
+    h = np.ascontiguousarray(G["homography"]["h"], dtype=float)
+    for pt in G["homography"]["points"]:
+        r, J = np.zeros(2), np.zeros((2, 8))
+        oracle.orc_homography_eval(dptr(h), pt["x"], pt["y"], pt["u"], pt["v"], dptr(r), dptr(J))
+        assert np.abs(r - np.array(pt["r"])).max() <= 1e-10 and rel(J, np.array(pt["J"])) <= 1e-10
