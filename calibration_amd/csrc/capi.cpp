@@ -218,6 +218,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     if (const char* env = std::getenv("CBA_MODEB_MOMENTS")) e.modeb_moments = std::atoi(env);
     e.blk_s.alloc(d.n_blocks);
     e.scalar_out.alloc(8);
+    e.cost_part.alloc(static_cast<size_t>(2 * ((d.n_blocks + 2047) / 2048 + 1)));  // allocated here: launch_cost may run inside a graph capture
     CBA_HIP(hipStreamSynchronize(e.stream));
     init_lm_state(e, d);
     warm_lm(e);

@@ -147,6 +147,7 @@ struct Engine {
     DevBuf<Tile> tilesA, tilesB;
     DevBuf<int64_t> d_blk_tile_off;
     DevBuf<double> partial, blk_acc, blk_s, scalar_out;
+    DevBuf<double> cost_part; // [2 * ceil(n_blocks / 2048)] partial cost pairs (only above 4096 blocks)
     DevBuf<double> blk_mom;   // [n_blocks][MomLayout::N] Mode B moment rows of the two-pose chains (kernels_reproj.hip)
     int modeb_moments = 1;    // 0 = accumulate the 12 pose columns directly (CBA_MODEB_MOMENTS=0, for A/B comparison)
 

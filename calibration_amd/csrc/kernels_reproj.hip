@@ -239,6 +239,40 @@ __global__ __launch_bounds__(256) void k_cost(int n_blocks, const double* __rest
     if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; }
 }
 
+// two-stage form for many blocks (C3: 32 000): every workgroup reduces 2048 blocks to one pair, k_cost_final adds the pairs in
+// order (fixed tree: deterministic)
+__global__ __launch_bounds__(256) void k_cost_partial(int n_blocks, const double* __restrict__ blk_s, double huber_delta,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[2][256];
+    double c = 0.0, ss = 0.0;
+    const int b0 = blockIdx.x * 2048;
+    const int b1 = b0 + 2048 < n_blocks ? b0 + 2048 : n_blocks;
+    for (int b = b0 + static_cast<int>(threadIdx.x); b < b1; b += 256) {
+        double rho, w;
+        huber(blk_s[b], huber_delta, &rho, &w);
+        c += 0.5 * rho;
+        ss += blk_s[b];
+    }
+    sh[0][threadIdx.x] = c;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+__global__ void k_cost_final(int n_part, const double* __restrict__ part, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double c = 0.0, ss = 0.0;
+    for (int k = 0; k < n_part; ++k) { c += part[2 * k]; ss += part[2 * k + 1]; }
+    out[0] = c;
+    out[1] = ss;
+}
+
 // ---- Mode B -----------------------------------------------------------------------------------
 // Per tile: H = sum J^T J (upper triangle, row-major packed), g = sum J^T r, s = sum |r|^2, all
 // UNWEIGHTED (the per-block Huber weight is a scalar applied when blocks are assembled).
@@ -539,7 +573,13 @@ void launch_resid(Engine& e) {
 }
 
 void launch_cost(Engine& e, double huber_delta) {
-    hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.scalar_out.p);
+    if (e.n_blocks > 4096) {
+        const int n_part = (e.n_blocks + 2047) / 2048;
+        if (e.cost_part.n < static_cast<size_t>(2 * n_part)) e.cost_part.alloc(static_cast<size_t>(2 * n_part));
+        hipLaunchKernelGGL(k_cost_partial, dim3(n_part), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.cost_part.p);
+        hipLaunchKernelGGL(k_cost_final, dim3(1), dim3(64), 0, e.stream, n_part, e.cost_part.p, e.scalar_out.p);
+    } else
+        hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.scalar_out.p);
     CBA_HIP(hipGetLastError());
 }
 

@@ -745,3 +745,16 @@ def test_unobserved_camera_on_gpu(gpu_lib, oracle):
     assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and helpers.param_diff(a, b) <= 2e-9
     assert np.array_equal(b.intr[2], idle[0]) and np.array_equal(b.cam_pose[2], idle[1])
     assert cov is None and cov2 is not None
+
+
+def test_cost_reduction_above_4096_blocks(gpu_lib, oracle):
+    """The cost kernel switches to a two-stage reduction above 4096 residual blocks (C3 has 32 000): 4400 blocks here, Huber
+    active on part of them, against the oracle; and the LM still solves the problem."""
+    sc = synth.scene_bundle(1100, 4, noise_px=0.4, seed=9)
+    assert sc.flat.n_blocks > 4096
+    with optim.ReprojHandle(sc.flat) as h:
+        for delta in (1.0, -1.0, 8.0):
+            c1 = h.cost(delta)
+            assert abs(c1 - helpers.oracle_cost(oracle, sc.flat, delta)) <= 1e-10 * c1
+        s = h.solve(options(compute_covariance=0, optimize_intrinsics=1))
+    assert s.success
