@@ -758,3 +758,29 @@ def test_cost_reduction_above_4096_blocks(gpu_lib, oracle):
             assert abs(c1 - helpers.oracle_cost(oracle, sc.flat, delta)) <= 1e-10 * c1
         s = h.solve(options(compute_covariance=0, optimize_intrinsics=1))
     assert s.success
+
+
+def test_end_to_end_seed_then_refine(gpu_lib):
+    """The calling pattern of the reference's intrinsics facade (src/pipeline/facades/intrinsics.cpp:100-136): per-view pose
+    seeds from a rough camera matrix (estimate_planar_pose), then the non-linear refinement, then the covariance — all on the
+    device: batched DLT seeds -> semi-DLT (K + poses, distortion by variable projection) -> optimize_intrinsics with the full
+    Brown-Conrady model.  planar_intrinsics_test.cpp:343-348 asks for +-5 px on such a pipeline; noise-free data must come back
+    exactly."""
+    from calibration_amd.geometry import pose_to_matrix
+
+    for noise, tol in ((0.0, 1e-6), (0.3, 5.0)):
+        sc = synth.scene_intrinsics(25, rows=9, cols=12, spacing=0.06, noise_px=noise, seed=31)
+        f = sc.flat
+        views = [np.c_[f.X[a:b], f.Y[a:b], f.u[a:b], f.v[a:b]] for a, b in zip(f.blk_offset[:-1], f.blk_offset[1:])]
+        K0 = sc.gt_intr.reshape(-1)[:5] * np.array([0.95, 1.04, 1.01, 0.99, 1.0])
+        seeds = optim.estimate_planar_pose_batch(views, K0)
+        sd = optim.optimize_intrinsics_semidlt(views, K0, seeds, optim.IntrinsicsOptimOptions(core=optim.OptimOptions(compute_covariance=False), num_radial=3))
+        assert sd.core.success
+        r = optim.optimize_intrinsics(views, sd.camera, sd.c_se3_t)
+        assert r.core.success and r.core.covariance is not None
+        err = np.abs(r.camera - sc.gt_intr.reshape(-1))
+        assert err[:4].max() <= tol and (noise > 0 or err[5:].max() <= 1e-7), (noise, err)
+        if noise > 0:  # every parameter within 6 sigma of the engine's own covariance (k3 is weakly determined on this board)
+            sig = np.sqrt(np.diag(r.core.covariance)[:10])
+            ok = sig > 0
+            assert (err[ok] <= 6 * sig[ok]).all(), (err, sig)
