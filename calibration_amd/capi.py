@@ -198,6 +198,8 @@ PROTOTYPES = {
         [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
          c_int32_p, c_double_p, C.c_int32, C.POINTER(CbaOptions), C.POINTER(CbaSummary), c_double_p, c_double_p, c_double_p],
     ),
+    "cba_estimate_homography_batch": (
+        C.c_int32, [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
     "cba_estimate_planar_pose_batch": (
         C.c_int32, [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cba_estimate_handeye_dlt": (C.c_int32, [C.c_int32, c_double_p, c_double_p, C.c_double, c_double_p]),

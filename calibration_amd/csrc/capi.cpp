@@ -743,6 +743,18 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
     });
 }
 
+cba_status cba_estimate_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                         const double* u, const double* v, double* h9, int32_t* success) {
+    return guarded([&] {
+        if (n_views <= 0 || !view_offset || !X || !Y || !u || !v || !h9 || !success) throw std::invalid_argument("null argument");
+        for (int i = 0; i < n_views; ++i)
+            if (view_offset[i + 1] < view_offset[i] || view_offset[i + 1] - view_offset[i] > 0x7fffffff)
+                throw std::invalid_argument("bad view offsets");
+        if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        dlt_homography_batch(n_views, view_offset, X, Y, u, v, h9, success, 0);
+    });
+}
+
 cba_status cba_estimate_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
                                           const double* u, const double* v, const double* kmtx5, double* pose7) {
     return guarded([&] {

@@ -209,6 +209,8 @@ void semidlt_solve(int n_views, const int64_t* view_offset, const double* X, con
                    double* kappa5, double* poses7, int num_radial, const double* bounds_lo, const double* bounds_hi,
                    const int32_t* fixed_idx, const double* fixed_val, int n_fixed, const cba_options* o, cba_summary* summary,
                    double* distortion, double* view_errors, double* cov, int device);
+void dlt_homography_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
+                          double* H9, int32_t* ok, int device);
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, double* pose7, int device);
 void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device);

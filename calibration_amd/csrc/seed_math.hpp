@@ -109,13 +109,15 @@ CBA_HD void seed_rotmat_to_quat(const double* R, double* q) {
     }
 }
 
-// The whole seed of one view.  pose7 = [qw qx qy qz tx ty tz] (identity for < 4 points, planarpose_linear.cpp:55-57).
+// Hartley-normalised DLT homography of one view (HomographyEstimator::fit -> normalize_and_estimate_homography,
+// src/estimation/linear/homographyestimator.cpp:17-87, 123-146) from target points (X, Y) to pixels normalised by
+// K = [fx fy cx cy skew] (K = [1 1 0 0 0]: raw pixels, i.e. estimate_homography's DLT path, homography.cpp:31-43).
+// H row-major = T_dst^-1 Hn T_src with Hn(2,2) = 1 (:70); like the reference, no final rescale of H itself.  Returns false (H untouched) for
+// fewer than 4 points or a non-finite result (fit returns nullopt).
 template <class Coop>
-CBA_HD void planar_seed_view(int n, const double* X, const double* Y, const double* u, const double* v, const double* K, Coop& co,
-                             double* pose7) {
-    pose7[0] = 1.0;
-    for (int k = 1; k < 7; ++k) pose7[k] = 0.0;
-    if (n < 4) return;
+CBA_HD bool dlt_homography_view(int n, const double* X, const double* Y, const double* u, const double* v, const double* K, Coop& co,
+                                double* H) {
+    if (n < 4) return false;
     const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], skew = K[4];
     // pass 1: centroids of the target points and of the normalised pixels
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -160,7 +162,7 @@ CBA_HD void planar_seed_view(int n, const double* X, const double* Y, const doub
     // smallest eigenvector by inverse iteration on G + 1e-14 trace I
     const double shift = 1e-14 * tr + 1e-300;
     for (int a = 0; a < 9; ++a) A[a * 9 + a] += shift;
-    if (!seed_chol9(A)) return;
+    if (!seed_chol9(A)) return false;
     double h[9] = {0.37, -0.61, 0.83, 0.29, 0.71, -0.43, 0.53, -0.19, 0.97};
     for (int it = 0; it < 8; ++it) {
         chol_solve_n<9>(A, h);
@@ -174,10 +176,23 @@ CBA_HD void planar_seed_view(int n, const double* X, const double* Y, const doub
     for (int a = 0; a < 9; ++a) Hn[a] = h[a] / h[8];
     const double Ts[9] = {ss, 0.0, -ss * csx, 0.0, ss, -ss * csy, 0.0, 0.0, 1.0};
     const double Tdi[9] = {1.0 / sd, 0.0, cdx, 0.0, 1.0 / sd, cdy, 0.0, 0.0, 1.0};
-    double T1[9], H[9];
+    double T1[9], Hf[9];
     mat3_mul(Hn, Ts, T1);
-    mat3_mul(Tdi, T1, H);
-    if (!(H[0] == H[0]) || fabs(H[0]) > 1.7e308) return;  // non-finite homography -> identity (fit returns nullopt)
+    mat3_mul(Tdi, T1, Hf);
+    for (int a = 0; a < 9; ++a)
+        if (!(Hf[a] == Hf[a]) || fabs(Hf[a]) > 1.7e308) return false;  // non-finite homography (fit returns nullopt)
+    for (int a = 0; a < 9; ++a) H[a] = Hf[a];
+    return true;
+}
+
+// The whole seed of one view.  pose7 = [qw qx qy qz tx ty tz] (identity for < 4 points, planarpose_linear.cpp:55-57).
+template <class Coop>
+CBA_HD void planar_seed_view(int n, const double* X, const double* Y, const double* u, const double* v, const double* K, Coop& co,
+                             double* pose7) {
+    pose7[0] = 1.0;
+    for (int k = 1; k < 7; ++k) pose7[k] = 0.0;
+    double H[9];
+    if (!dlt_homography_view(n, X, Y, u, v, K, co, H)) return;
     if (fabs(H[8]) > 1e-15) {  // planarpose_linear.cpp:72-74
         const double inv = 1.0 / H[8];
         for (int a = 0; a < 9; ++a) H[a] *= inv;

@@ -624,6 +624,21 @@ def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t=None, opts: O
     return IntrinsicsOptimizationResult(result_core(s, c), camera, [pose_to_matrix(p) for p in poses], [float(e) for e in ve[:nv]], dist)
 
 
+def estimate_homography_batch(views):
+    """Batched estimate_homography (DLT path, homography.cpp:31-43): -> (list of 3x3 H, list of success flags)."""
+    lib = capi.load_library()
+    nv = len(views)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in views]
+    off = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    H = np.zeros((max(nv, 1), 9))
+    ok = np.zeros(max(nv, 1), dtype=np.int32)
+    capi.check(lib, lib.cba_estimate_homography_batch(nv, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(H), i32ptr(ok)))
+    return [H[i].reshape(3, 3).copy() for i in range(nv)], [bool(k) for k in ok[:nv]]
+
+
 def estimate_planar_pose_batch(views, intrinsics) -> List[np.ndarray]:
     """Batched estimate_planar_pose (linear/planarpose.h, planarpose_linear.cpp:54-76) on the GPU: one 4x4 c_T_t per view."""
     lib = capi.load_library()

@@ -315,6 +315,14 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
                                            const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
                                            cba_summary* summary, double* distortion, double* view_errors, double* cov);
 
+/* estimate_homography, DLT path (include/calib/estimation/linear/homography.h, src/estimation/optim/homography.cpp:31-43 ->
+ * HomographyEstimator::fit, src/estimation/linear/homographyestimator.cpp:123-146): Hartley-normalised DLT of every view in one
+ * launch.  h9 [n_views][9] row-major = T_dst^-1 Hn T_src with Hn(2,2) = 1, returned WITHOUT a final rescale exactly as the reference
+ * does (homographyestimator.cpp:70, 79-87); success [n_views] = 0 where fit fails (< 4 correspondences, non-finite H), h9 is then
+ * the identity.  The natural seed of cba_optimize_homography_batch. */
+cba_status cba_estimate_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
+                                         const double* u, const double* v, double* h9, int32_t* success);
+
 /* estimate_planar_pose (include/calib/estimation/linear/planarpose.h:38-110, src/estimation/linear/planarpose_linear.cpp:54-76)
  * for a batch of views in one launch: pixels normalised by K = [fx, fy, cx, cy, skew], Hartley-normalised DLT homography
  * (src/estimation/linear/homographyestimator.cpp:17-87), pose_from_homography_normalized (planarpose_linear.cpp:17-52).

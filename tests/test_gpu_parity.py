@@ -784,3 +784,25 @@ def test_end_to_end_seed_then_refine(gpu_lib):
             sig = np.sqrt(np.diag(r.core.covariance)[:10])
             ok = sig > 0
             assert (err[ok] <= 6 * sig[ok]).all(), (err, sig)
+
+
+def test_homography_dlt_batch_then_refine_on_gpu(gpu_lib):
+    """estimate_homography (DLT) -> optimize_homography, both batched on the device, as homography_test.cpp:50-93 chains them."""
+    from tests.planar_seed import homography_dlt
+
+    views, truth = [], []
+    for i, n in enumerate([4, 5, 50, 64, 65, 400]):
+        view, H = helpers.homography_scene(n, 0.0 if i % 2 == 0 else 0.1, seed=300 + i)
+        views.append(view)
+        truth.append(H)
+    views.append(views[0][:3])  # < 4 correspondences: fit fails
+    Hs, ok = optim.estimate_homography_batch(views)
+    assert ok == [True] * 6 + [False] and np.array_equal(Hs[-1], np.eye(3))
+    for view, H, Ht in zip(views[:-1], Hs, truth):
+        Hr = homography_dlt(view[:, :2], view[:, 2:])
+        # (as in the reference, only the NORMALISED solve has H22 = 1: T_dst^-1 Hn T_src is returned without a final rescale,
+        #  and optimize_homography then reads its first 8 entries as they are — homographyestimator.cpp:70, 79-87; homography.cpp:79-84)
+        assert np.abs(H - Hr).max() <= 1e-8 * np.abs(Hr).max()
+    res = optim.optimize_homography_batch(views[:-1], Hs[:-1])
+    for r, Ht, view in zip(res, truth, views[:-1]):
+        assert r.core.success and helpers.is_approx(r.homography, Ht, 1e-2 if len(view) > 5 else 5e-2)
