@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP engine against the CPU oracle: random chain / camera model / sizes / noise / stage switches /
+loss, LM to epsilon = 1e-12, compared on termination, iterations, cost and parameters.  Not part of the test suite (it is a
+search for disagreements, run with spare GPU time); prints one JSON summary line.  usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from calibration_amd import optim, synth
+from tests import helpers
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+orc = helpers.load_oracle()
+worst, bad, t0 = 0.0, [], time.time()
+for i in range(n_cases):
+    kind = ["intr", "ext", "bundle"][int(rng.integers(0, 3))]
+    model = int(rng.integers(0, 2))
+    seed = int(rng.integers(1, 1 << 20))
+    noise = float(rng.choice([0.0, 0.1, 0.5]))
+    okw = dict(huber_delta=float(rng.choice([1.0, -1.0, 0.3, 3.0])), optimize_skew=int(rng.integers(0, 2)))
+    if kind != "intr":
+        okw.update(optimize_intrinsics=int(rng.integers(0, 2)), optimize_extrinsics=int(rng.integers(0, 2)))
+    if kind == "bundle":
+        okw.update(optimize_target_pose=int(rng.integers(0, 2)))
+    nv, nc = int(rng.integers(4, 9)), int(rng.integers(1, 4))
+    rows, cols = int(rng.integers(4, 10)), int(rng.integers(5, 12))
+    mk = {"intr": lambda: synth.scene_intrinsics(nv, rows=rows, cols=cols, spacing=0.08, model=model, noise_px=noise, seed=seed),
+          "ext": lambda: synth.scene_extrinsics(nv, max(2, nc), rows=rows, cols=cols, spacing=0.08, model=model, noise_px=noise, seed=seed),
+          "bundle": lambda: synth.scene_bundle(nv + 4, nc, rows=rows, cols=cols, spacing=0.04, model=model, noise_px=noise, seed=seed)}[kind]
+    a, b = mk(), mk()
+    o = helpers.options(epsilon=1e-12, **okw)
+    sa = helpers.oracle_solve(orc, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+    pd = helpers.param_diff(a.flat, b.flat)
+    # Scheimpflug / free skew: near-degenerate directions amplify rounding between two correct solvers
+    tol = 1e-5 if model == 1 else (5e-8 if okw.get("optimize_skew") else 2e-9)
+    rec = dict(i=i, kind=kind, model=model, seed=seed, noise=noise, okw=okw, nv=nv, nc=nc, grid=[rows, cols], term=[int(sa.termination), int(sb.termination)],
+               iters=[int(sa.iterations), int(sb.iterations)], cost=[float(sa.final_cost), float(sb.final_cost)], param_diff=pd)
+    ok = sa.termination == sb.termination and abs(sa.iterations - sb.iterations) <= 2 and pd <= tol and \
+        abs(sa.final_cost - sb.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
+    if not ok:
+        bad.append(rec)
+    if model == 0 and not okw.get("optimize_skew"):
+        worst = max(worst, pd)
+print(json.dumps(dict(cases=n_cases, disagreements=len(bad), worst_param_diff_pinhole_noskew=worst, seconds=time.time() - t0, bad=bad[:10])))
