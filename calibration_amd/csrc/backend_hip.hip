@@ -188,6 +188,51 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
         for (int q = 0; q < 4; ++q) out[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
 }
 
+// The same contraction on the matrix cores, used when the shared block is a real contraction (nsh >= 64: the 8-camera rig of
+// BASELINE config 3 has nsh = 128, K = 6 x #views).  One workgroup = one 64x64 output tile over a chunk of VCHUNK views: the
+// chunk's 6 * VCHUNK = 48 rows of Z are staged in LDS, every wavefront owns a 16 x 64 strip = four 16x16 accumulators and
+// issues v_mfma_f64_16x16x4_f64 over the 12 four-row steps (A[i][k]: lane i = l & 15, k = l >> 4; B[k][j] likewise;
+// D: col = l & 15, row = (l >> 4) + 4 reg).  fp64 MFMA runs at the vector-FMA rate on MI355X (78.6 TFLOP/s both), so this is
+// about USING the matrix pipe where the north-star asks for it, not about speed: the kernel is ~40 us of a 6 ms LM step.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int SYRK_ROWS = 6 * VCHUNK;  // 48, a multiple of 4
+
+__global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_views, int nsh, int n_tiles,
+                                                         const int32_t* __restrict__ view_cam_blk,
+                                                         const double* __restrict__ blk_Z, double* __restrict__ partial) {
+    __shared__ double Zi[SYRK_ROWS][64], Zj[SYRK_ROWS][64];
+    int pair = blockIdx.y, ti = 0;
+    while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
+    const int tj = ti + pair;
+    const int i0 = ti * 64, j0 = tj * 64;
+    const int v0 = blockIdx.x * VCHUNK;
+    for (int idx = threadIdx.x; idx < 2 * SYRK_ROWS * 64; idx += 256) {
+        const int which = idx / (SYRK_ROWS * 64), rem = idx - which * (SYRK_ROWS * 64);
+        const int row = rem >> 6, c = rem & 63;
+        const int v = v0 + row / 6, k = row % 6;
+        const double val = v < n_views ? z_entry(d, view_cam_blk, blk_Z, v, (which ? j0 : i0) + c, k, nsh) : 0.0;
+        if (which) Zj[row][c] = val; else Zi[row][c] = val;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    v4f64 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int step = 0; step < SYRK_ROWS / 4; ++step) {
+        const int r = 4 * step + lk;
+        const double a = Zi[r][wave * 16 + li];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zj[r][c * 16 + li], acc[c], 0, 0, 0);
+    }
+    double* out = partial + (static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * 4096;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) out[(wave * 16 + lk + 4 * reg) * 64 + c * 16 + li] = acc[c][reg];
+}
+
 // partial[chunk][g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k]
 __global__ void k_schur_gvec(SchurDims d, int n_views, int nsh, const int32_t* __restrict__ view_cam_blk,
                              const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
@@ -224,6 +269,7 @@ struct HipLMState {
     Structure s;
     SchurDims dims;
     int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
+    int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
     DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
     DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
     DevBuf<int32_t> link_blk;
@@ -360,8 +406,12 @@ struct HipBackend final : Backend {
                            st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.lmp.p, constrained ? 1 : 0,
                            e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                            st.view_gmax.p, st.nfail.p);
-        hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
-                           st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
+        if (n >= 64 && st.syrk_mfma)
+            hipLaunchKernelGGL(k_schur_syrk_mfma, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
+                               st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
+        else
+            hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
+                               st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
                            st.syrk_partial.p, st.schur_pack.p);
@@ -540,6 +590,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d) {
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_schur_view));
         warm_reproj_kernels();
     }
+    if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);
         st->graphs_ok = v != 0;

@@ -806,3 +806,24 @@ def test_homography_dlt_batch_then_refine_on_gpu(gpu_lib):
     res = optim.optimize_homography_batch(views[:-1], Hs[:-1])
     for r, Ht, view in zip(res, truth, views[:-1]):
         assert r.core.success and helpers.is_approx(r.homography, Ht, 1e-2 if len(view) > 5 else 5e-2)
+
+
+def test_eight_camera_rig_schur_contraction_on_mfma(gpu_lib, oracle, monkeypatch):
+    """BASELINE config 3's rig (8 cameras: shared block 8 x 16 = 128 wide): the Schur contraction S -= sum_v Z_v^T Z_v runs on
+    v_mfma_f64_16x16x4_f64 (k_schur_syrk_mfma) when the shared block is >= 64 wide.  LM parity against the dense oracle, and
+    against the register-blocked VALU form (CBA_SYRK_MFMA=0)."""
+    def run(mfma):
+        monkeypatch.setenv("CBA_SYRK_MFMA", str(mfma))
+        sc = synth.scene_extrinsics(11, 8, rows=6, cols=7, spacing=0.08, noise_px=0.2, seed=137)
+        with optim.ReprojHandle(sc.flat) as h:
+            s = h.solve(options(epsilon=1e-12, compute_covariance=0))
+        return sc, s
+
+    a = synth.scene_extrinsics(11, 8, rows=6, cols=7, spacing=0.08, noise_px=0.2, seed=137)
+    sa = helpers.oracle_solve(oracle, a.flat, options(epsilon=1e-12, compute_covariance=0))
+    (b, sb), (c, sc_) = run(1), run(0)
+    for x, sx in ((b, sb), (c, sc_)):
+        assert sx.termination == sa.termination and abs(sx.iterations - sa.iterations) <= 2
+        assert abs(sx.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
+        assert helpers.param_diff(a.flat, x.flat) <= 2e-9
+    assert helpers.param_diff(b.flat, c.flat) <= 1e-10
