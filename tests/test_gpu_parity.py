@@ -827,3 +827,19 @@ def test_eight_camera_rig_schur_contraction_on_mfma(gpu_lib, oracle, monkeypatch
         assert abs(sx.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
         assert helpers.param_diff(a.flat, x.flat) <= 2e-9
     assert helpers.param_diff(b.flat, c.flat) <= 1e-10
+
+
+def test_plain_c_example_runs(gpu_lib, tmp_path):
+    """examples/c_api_demo.c: the C ABI used from plain C (no Python, no torch in the process)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, libdir = str(tmp_path / "demo"), os.path.join(root, "calibration_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_api_demo.c"), "-L", libdir,
+                    "-lcalibba", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    vals = dict(zip(("fx", "fy", "cx", "cy"), [float(t) for t in r.stdout.split("fx")[1].replace("fy", " ").replace("cx", " ").replace("cy", " ").split("(")[0].split()]))
+    assert abs(vals["fx"] - 1000) < 1e-5 and abs(vals["fy"] - 1005) < 1e-5 and abs(vals["cx"] - 640) < 1e-5 and abs(vals["cy"] - 360) < 1e-5
+    assert "success 1" in r.stdout

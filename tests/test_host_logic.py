@@ -692,3 +692,19 @@ def test_camera_without_observations_and_ragged_rig(oracle, hostmath):
     assert np.array_equal(d0 == 0, np.diag(cov1) == 0)
     nz = d0 > 0
     assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-5
+
+
+def test_header_is_plain_c_and_the_c_example_links(lib, tmp_path):
+    """include/calibba.h must stay a C header (the drop-in boundary is a C ABI): the plain-C example compiles with
+    -std=c99 -pedantic, links against libcalibba.so and, on a machine without a GPU, fails loudly with the no-device message."""
+    import subprocess
+
+    src = os.path.join(ROOT, "examples", "c_api_demo.c")
+    obj = str(tmp_path / "demo.o")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj], check=True)
+    exe = str(tmp_path / "demo")
+    libdir = os.path.join(ROOT, "calibration_amd", "lib")
+    subprocess.run(["gcc", obj, "-L", libdir, "-lcalibba", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe], check=True)
+    if lib.cba_device_count() <= 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device visible" in r.stderr
