@@ -8,6 +8,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -69,7 +72,95 @@ static void upload_params(Engine& e) {
     e.target[0].upload(e.h_target.data(), e.h_target.size(), e.stream);
 }
 
+namespace {
+struct PhaseTimer {  // CBA_CREATE_TIMING=1: print where cba_reproj_create spends its time (host staging vs PCIe vs set-up)
+    bool on = getenv("CBA_CREATE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cba create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
+// run fn(b) for b in [0, n) on up to 8 host threads (contiguous ranges); small n stays on the calling thread
+template <class F>
+static void parallel_blocks(int n, F&& fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min<int>({8, static_cast<int>(hw ? hw : 1), n / 64}));
+    if (nt == 1) { for (int b = 0; b < n; ++b) fn(b); return; }
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::mutex mu;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            try { for (int b = static_cast<int>(static_cast<int64_t>(n) * t / nt); b < static_cast<int>(static_cast<int64_t>(n) * (t + 1) / nt); ++b) fn(b); }
+            catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+        });
+    for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// Scatter per-block host arrays into a zero-padded device array of `len` doubles through two page-locked bounce buffers:
+// while chunk k travels over PCIe (hipMemcpyAsync from pinned memory) host threads assemble chunk k + 1.
+struct StagedUpload {
+    static constexpr int64_t CHUNK = int64_t(1) << 23;  // 8 Mi doubles = 64 MiB
+    hipStream_t stream;
+    PinnedBuf<double> pin[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    explicit StagedUpload(hipStream_t s) : stream(s) {
+        for (auto& ev : done) CBA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    ~StagedUpload() { for (auto& ev : done) if (ev) (void)hipEventDestroy(ev); }
+    std::vector<double> small;  // arrays under 4 MiB: one pageable staging buffer (page-locking memory costs ~1 ms, more than it saves)
+    void reserve(int64_t longest) {
+        if (longest < (int64_t(1) << 19)) return;
+        const size_t c = static_cast<size_t>(std::min<int64_t>(CHUNK, longest));
+        pin[0].reserve(c); pin[1].reserve(c);
+    }
+    template <class Off, class Len, class Src>
+    void run(double* dst, int64_t len, int n_blocks, Off&& offset_of, Len&& length_of, Src&& source_of) {
+        // blocks in increasing destination order (offsets are monotone in b for the blocks that are stored)
+        std::vector<int> order;
+        for (int b = 0; b < n_blocks; ++b) if (offset_of(b) >= 0) order.push_back(b);
+        if (!pin[0].p) {
+            small.assign(static_cast<size_t>(len), 0.0);
+            for (int b : order) std::memcpy(&small[static_cast<size_t>(offset_of(b))], source_of(b), sizeof(double) * static_cast<size_t>(length_of(b)));
+            CBA_HIP(hipMemcpyAsync(dst, small.data(), sizeof(double) * static_cast<size_t>(len), hipMemcpyHostToDevice, stream));
+            CBA_HIP(hipStreamSynchronize(stream));
+            return;
+        }
+        const int64_t chunk = static_cast<int64_t>(pin[0].n);
+        size_t first = 0;  // first block that may intersect the current chunk
+        int k = 0;
+        for (int64_t c0 = 0; c0 < len; c0 += chunk, ++k) {
+            const int64_t c1 = std::min(len, c0 + chunk);
+            double* buf = pin[k & 1].p;
+            if (k >= 2) CBA_HIP(hipEventSynchronize(done[k & 1]));  // the copy that last used this bounce buffer
+            while (first < order.size() && offset_of(order[first]) + length_of(order[first]) <= c0) ++first;
+            size_t last = first;
+            while (last < order.size() && offset_of(order[last]) < c1) ++last;
+            std::memset(buf, 0, sizeof(double) * static_cast<size_t>(c1 - c0));
+            const int nb = static_cast<int>(last - first);
+            auto copy_block = [&](int i) {
+                const int b = order[first + i];
+                const int64_t o = offset_of(b), n = length_of(b);
+                const int64_t lo = std::max(o, c0), hi = std::min(o + n, c1);
+                if (hi > lo) std::memcpy(buf + (lo - c0), source_of(b) + (lo - o), sizeof(double) * static_cast<size_t>(hi - lo));
+            };
+            if (c1 - c0 >= (int64_t(1) << 20)) parallel_blocks(nb, copy_block);
+            else for (int i = 0; i < nb; ++i) copy_block(i);
+            CBA_HIP(hipMemcpyAsync(dst + c0, buf, sizeof(double) * static_cast<size_t>(c1 - c0), hipMemcpyHostToDevice, stream));
+            CBA_HIP(hipEventRecord(done[k & 1], stream));
+        }
+        CBA_HIP(hipStreamSynchronize(stream));
+    }
+};
+
 static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
+    PhaseTimer pt;
     if (const char* ev = getenv("CBA_EVAL_VARIANT")) e.eval_variant = atoi(ev);
     if (const char* eb = getenv("CBA_EVAL_BLOCKED")) e.eval_blocked = atoi(eb);
     Structure st;
@@ -106,69 +197,73 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     CBA_HIP(hipEventCreate(&e.ev0));
     CBA_HIP(hipEventCreate(&e.ev1));
 
+    pt.lap("structure + device + stream");
     // ---- observations: padded SoA; X, Y deduplicated across blocks ------------------------------------
     {
-        // residual blocks whose (X, Y) lists are bitwise identical share one device copy
+        // residual blocks whose (X, Y) lists are bitwise identical share one device copy.  Hashing and the byte-for-byte
+        // confirmation run on a few host threads (at C3 this is 2.6 GB of target points: 0.4 s on one core).
         e.xy_offset.assign(d.n_blocks, 0);
-        std::unordered_map<uint64_t, std::vector<int>> seen;
-        std::vector<int> owner(d.n_blocks, -1);
-        int64_t xy_pad = 0;
-        for (int b = 0; b < d.n_blocks; ++b) {
+        std::vector<uint64_t> hashes(d.n_blocks);
+        parallel_blocks(d.n_blocks, [&](int b) {
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
-            const double* bx = d.X + e.blk_offset[b];
-            const double* by = d.Y + e.blk_offset[b];
             uint64_t hsh = 1469598103934665603ULL ^ static_cast<uint64_t>(n);
-            auto mix = [&](const double* p) {
+            for (const double* p : {d.X + e.blk_offset[b], d.Y + e.blk_offset[b]})
                 for (int64_t i = 0; i < n; ++i) {
                     uint64_t w;
                     std::memcpy(&w, p + i, 8);
                     hsh = (hsh ^ w) * 1099511628211ULL;
                     hsh ^= hsh >> 29;
                 }
-            };
-            mix(bx); mix(by);
-            int found = -1;
-            for (int cand : seen[hsh]) {
-                const int64_t nc = e.blk_offset[cand + 1] - e.blk_offset[cand];
-                if (nc == n && std::memcmp(d.X + e.blk_offset[cand], bx, sizeof(double) * n) == 0 &&
-                    std::memcmp(d.Y + e.blk_offset[cand], by, sizeof(double) * n) == 0) { found = cand; break; }
-            }
-            if (found >= 0) {
-                e.xy_offset[b] = e.xy_offset[found];
+            hashes[b] = hsh;
+        });
+        // candidate owner = the first block with the same (hash, length); confirmed below
+        std::unordered_map<uint64_t, int> first_of;
+        std::vector<int> cand(d.n_blocks, -1);
+        for (int b = 0; b < d.n_blocks; ++b) {
+            const auto it = first_of.find(hashes[b]);
+            if (it == first_of.end()) first_of.emplace(hashes[b], b);
+            else cand[b] = it->second;
+        }
+        std::vector<char> same(d.n_blocks, 0);
+        parallel_blocks(d.n_blocks, [&](int b) {
+            const int c = cand[b];
+            if (c < 0) return;
+            const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b], nc = e.blk_offset[c + 1] - e.blk_offset[c];
+            same[b] = nc == n && std::memcmp(d.X + e.blk_offset[c], d.X + e.blk_offset[b], sizeof(double) * n) == 0 &&
+                      std::memcmp(d.Y + e.blk_offset[c], d.Y + e.blk_offset[b], sizeof(double) * n) == 0;
+        });
+        std::vector<int> owner(d.n_blocks, -1);
+        int64_t xy_pad = 0;
+        for (int b = 0; b < d.n_blocks; ++b) {
+            if (cand[b] >= 0 && same[b]) {  // (a hash collision with different bytes simply keeps its own copy)
+                e.xy_offset[b] = e.xy_offset[cand[b]];
             } else {
-                seen[hsh].push_back(b);
+                const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
                 owner[b] = b;
                 e.xy_offset[b] = xy_pad;
                 xy_pad += (n + 1) & ~int64_t(1);
                 ++e.n_xy_unique_blocks;
             }
         }
+        pt.lap("hash + dedup of X, Y");
         e.ld_xy = std::max<int64_t>(256, (xy_pad + 255) & ~int64_t(255));
-        std::vector<double> buf;
+        e.X.alloc(e.ld_xy); e.Y.alloc(e.ld_xy); e.u.alloc(e.ld); e.v.alloc(e.ld);
+        // padded SoA arrays go up through two page-locked bounce buffers: host threads fill chunk k+1 while chunk k is in flight
+        StagedUpload up(e.stream);
+        up.reserve(std::max(e.ld, e.ld_xy));
         for (int a = 0; a < 2; ++a) {
-            buf.assign(static_cast<size_t>(e.ld_xy), 0.0);
             const double* src = a == 0 ? d.X : d.Y;
-            for (int b = 0; b < d.n_blocks; ++b)
-                if (owner[b] == b)
-                    std::memcpy(&buf[e.xy_offset[b]], src + e.blk_offset[b],
-                                sizeof(double) * static_cast<size_t>(e.blk_offset[b + 1] - e.blk_offset[b]));
-            DevBuf<double>& dst = a == 0 ? e.X : e.Y;
-            dst.alloc(e.ld_xy);
-            dst.upload(buf.data(), buf.size(), e.stream);
-            CBA_HIP(hipStreamSynchronize(e.stream));
+            up.run(a == 0 ? e.X.p : e.Y.p, e.ld_xy, d.n_blocks,
+                   [&](int b2) { return owner[b2] == b2 ? e.xy_offset[b2] : int64_t(-1); },
+                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return src + e.blk_offset[b2]; });
         }
         for (int a = 0; a < 2; ++a) {
-            buf.assign(static_cast<size_t>(e.ld), 0.0);
             const double* src = a == 0 ? d.u : d.v;
-            for (int b = 0; b < d.n_blocks; ++b)
-                std::memcpy(&buf[e.pad_offset[b]], src + e.blk_offset[b],
-                            sizeof(double) * static_cast<size_t>(e.blk_offset[b + 1] - e.blk_offset[b]));
-            DevBuf<double>& dst = a == 0 ? e.u : e.v;
-            dst.alloc(e.ld);
-            dst.upload(buf.data(), buf.size(), e.stream);
-            CBA_HIP(hipStreamSynchronize(e.stream));
+            up.run(a == 0 ? e.u.p : e.v.p, e.ld, d.n_blocks, [&](int b2) { return e.pad_offset[b2]; },
+                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return src + e.blk_offset[b2]; });
         }
     }
+    pt.lap("stage + upload X, Y, u, v");
     // ---- tile tables ----------------------------------------------------------------------------
     {
         std::vector<Tile> ta, tb;
@@ -193,6 +288,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
         e.d_blk_view.alloc(d.n_blocks); e.d_blk_view.upload(e.blk_view.data(), e.blk_view.size(), e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
     }
+    pt.lap("tile tables");
     // ---- parameters -----------------------------------------------------------------------------
     e.h_intr.assign(d.intr, d.intr + static_cast<size_t>(d.n_cams) * e.PI);
     e.h_cam.assign(7 * static_cast<size_t>(d.n_cams), 0.0);
@@ -220,8 +316,11 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     e.scalar_out.alloc(8);
     e.cost_part.alloc(static_cast<size_t>(2 * ((d.n_blocks + 2047) / 2048 + 1)));  // allocated here: launch_cost may run inside a graph capture
     CBA_HIP(hipStreamSynchronize(e.stream));
+    pt.lap("parameters + buffers");
     init_lm_state(e, d);
+    pt.lap("LM state");
     warm_lm(e);
+    pt.lap("warm-up pass");
 }
 
 extern "C" {
