@@ -150,6 +150,7 @@ PROTOTYPES = {
     "cba_reproj_block_normal_eq": (C.c_int32, [C.c_void_p, c_double_p]),
     "cba_reproj_block_normal_eq_size": (C.c_int64, [C.c_void_p]),
     "cba_reproj_solve": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), C.POINTER(CbaSummary)]),
+    "cba_reproj_set_lm_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cba_reproj_covariance_dim": (C.c_int64, [C.c_void_p]),
     "cba_reproj_covariance": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), c_double_p]),
     "cba_reproj_covariance_shared_dim": (C.c_int64, [C.c_void_p]),

@@ -16,6 +16,7 @@
 
 #include "engine.hpp"
 #include "lm_core.hpp"
+#include "lm_state.hpp"
 #include "schur_math.hpp"
 
 namespace cba {
@@ -132,14 +133,6 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
                                     gp + 6 * static_cast<int64_t>(v), blk_Z, &gm);
     gmax[v] = ok ? gm : 0.0;
     if (!ok) atomicAdd(nfail, 1);
-}
-
-__device__ __forceinline__ double z_entry(const SchurDims& d, const int32_t* __restrict__ view_cam_blk,
-                                          const double* __restrict__ blk_Z, int v, int g, int k, int nsh) {
-    if (g >= nsh) return 0.0;
-    const int cam = g / d.PC, lc = g - cam * d.PC;
-    const int b = view_cam_blk[static_cast<int64_t>(v) * d.n_cams + cam];
-    return b < 0 ? 0.0 : blk_Z[(static_cast<int64_t>(b) * 6 + k) * d.PSH + lc];
 }
 
 // grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
@@ -264,40 +257,7 @@ __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ 
 
 static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(std::max<int64_t>(1, (n + per - 1) / per)); }
 
-// ---- Backend on an Engine ------------------------------------------------------------------------
-struct HipLMState {
-    Structure s;
-    SchurDims dims;
-    int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
-    int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
-    DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
-    DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
-    DevBuf<int32_t> link_blk;
-    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
-    DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
-    PinnedBuf<double> pin, pin_ne, pin_tr;  // host staging of every per-step D2H result (one stream sync per stage)
-    PinnedBuf<int32_t> pin_i;
-    // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
-    // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
-    // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches
-    // travels through memory the graph's own copy nodes read at execution time: [radius, init_scale] and the shared step
-    // in pinned host buffers.  Values baked into kernel arguments (huber, constrained, fp32 mode) key the graph.
-    struct GraphSlot {
-        hipGraphExec_t exec = nullptr;
-        double huber = 0.0;
-        int constrained = -1, scalar = -1;
-        int uses = 0;  // plain launches of this stage with the current key so far
-        ~GraphSlot() { if (exec) (void)hipGraphExecDestroy(exec); }
-    };
-    GraphSlot g_new, g_schur, g_trial;
-    bool graphs_ok = true;
-    int graph_after = 200;// capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
-                          // than a solve, so a stage runs as plain launches until it has been used this many times with
-                          // the same key — i.e. on handles that are solved again and again (CBA_LM_GRAPH=<n>, 1 = at once, 0 = never)
-    DevBuf<double> lmp;          // device [radius, init_scale]
-    PinnedBuf<double> pin_lmp, pin_delta;
-};
-
+// ---- Backend on an Engine (state: lm_state.hpp) -------------------------------------------------------
 struct HipBackend final : Backend {
     Engine& e;
     HipLMState& st;
@@ -533,8 +493,6 @@ struct HipBackend final : Backend {
 };
 
 // ---- engine glue -----------------------------------------------------------------------------------
-static HipLMState* lm_state(Engine& e) { return reinterpret_cast<HipLMState*>(e.lm_state); }
-
 void destroy_lm_state(Engine& e) {
     delete lm_state(e);
     e.lm_state = nullptr;
@@ -608,7 +566,24 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d) {
     e.blk_Z.alloc(static_cast<size_t>(std::max(1, s.n_blocks)) * 6 * s.PSH);
     e.blk_Z.zero(e.stream);
     e.delta_sh.alloc(s.nsh);
+    // resident LM (resident_lm.hip)
+    up64(st->cam_off, s.cam_off);
+    st->res_active.alloc(std::max(1, s.nsh));
+    st->res_cam_var.alloc(std::max(1, s.n_cams));
+    st->res_Hcc.alloc(static_cast<size_t>(s.nsh) * s.nsh);
+    st->res_Ssch.alloc(static_cast<size_t>(s.nsh) * s.nsh);
+    st->res_out.alloc(32);
+    // crossover with the host-driven iteration (tools/exp_resident.py): one CU runs Mode B at ~16 ns per
+    // observation for P = 16 and ~50 ns for the two-pose chains (276-325 accumulators in six passes)
+    st->resident_max_obs = s.chain == CBA_CHAIN_INTRINSIC ? 8192 : (s.chain == CBA_CHAIN_EXTRINSIC ? 2048 : 1024);
+    if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);
+    if (const char* env = std::getenv("CBA_LM_RESIDENT_MAX_OBS")) st->resident_max_obs = std::atoll(env);
     CBA_HIP(hipStreamSynchronize(e.stream));
+}
+
+void set_lm_mode(Engine& e, int mode) {
+    if (mode < 0 || mode > 2) throw std::invalid_argument("lm mode: 0 host-driven, 1 automatic, 2 resident whenever possible");
+    lm_state(e)->resident_mode = mode;
 }
 
 void engine_allreduce(Engine& e, double* buf, int64_t n) {
@@ -666,6 +641,11 @@ static LMDriver make_driver(Engine& e, HipBackend& be) {
 // one-time cost on ROCm (code-object load, ~0.1-0.3 ms of per-kernel set-up) that added ~8 ms to the first solve of
 // a small problem; a handle that exists has paid it.  Results are discarded (every solve re-evaluates from the parameters).
 void warm_lm(Engine& e) {
+    {   // a handle the resident kernel will serve warms that kernel instead (default options decide; other solves still work)
+        cba_options o{};
+        o.max_iterations = 1;
+        if (resident_lm_eligible(e, o)) { resident_lm_warm(e); return; }
+    }
     HipBackend be(e, *lm_state(e));
     const Structure& s = lm_state(e)->s;
     if (s.n_blocks == 0) return;
@@ -686,6 +666,10 @@ void warm_lm(Engine& e) {
 }
 
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
+    if (resident_lm_eligible(e, o)) {  // small problem: the whole iteration in one kernel launch
+        resident_lm_solve(e, o, out);
+        return;
+    }
     HipBackend be(e, *lm_state(e));
     LMDriver drv = make_driver(e, be);
     drv.solve(o, out);

@@ -632,6 +632,10 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
     });
 }
 
+cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode) {
+    return guarded([&] { set_lm_mode(*as_engine(h), mode); });
+}
+
 int64_t cba_reproj_covariance_dim(const cba_reproj* h) { return h ? covariance_dim(*reinterpret_cast<const Engine*>(h)) : 0; }
 
 cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double* cov) {

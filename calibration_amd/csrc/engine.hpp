@@ -66,8 +66,8 @@ struct DevBuf {
     void upload(const T* src, size_t count, hipStream_t s) {
         if (count) CBA_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
     }
-    void download(T* dst, size_t count, hipStream_t s) const {
-        if (count) CBA_HIP(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    void download(T* dst, size_t count, hipStream_t s, size_t first = 0) const {
+        if (count) CBA_HIP(hipMemcpyAsync(dst, p + first, count * sizeof(T), hipMemcpyDeviceToHost, s));
     }
     void zero(hipStream_t s) { CBA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
@@ -193,6 +193,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d);
 void destroy_lm_state(Engine& e);
 void warm_lm(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
+void set_lm_mode(Engine& e, int mode);  // 0 host-driven iteration, 1 automatic (default), 2 resident kernel whenever it can run the problem
 void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
 int64_t covariance_dim(const Engine& e);
 int64_t shared_covariance_dim(const Engine& e);

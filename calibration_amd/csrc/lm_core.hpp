@@ -107,6 +107,16 @@ class LMDriver {
         be_.set_view_fixed(fixed);
     }
 
+    // the constant / gauge masks of `o`, for a solver that runs the iteration itself (resident_lm.hip)
+    struct Masks {
+        std::vector<char> active, cam_var;
+        bool intr_var, target_var, constrained;
+    };
+    Masks masks(const cba_options& o) {
+        setup(o);
+        return Masks{active_, cam_var_, intr_var_, target_var_, constrained_};
+    }
+
     void solve(const cba_options& o, cba_summary* out) {
         const auto t0 = std::chrono::steady_clock::now();
         setup(o);

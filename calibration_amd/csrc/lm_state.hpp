@@ -1,0 +1,59 @@
+// lm_state.hpp — device-side LM / Schur state behind an Engine (backend_hip.hip builds it; resident_lm.hip reads it).
+#pragma once
+#include "engine.hpp"
+#include "schur_math.hpp"
+#include "structure.hpp"
+
+namespace cba {
+
+struct HipLMState {
+    Structure s;
+    SchurDims dims;
+    int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
+    int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
+    DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
+    DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
+    DevBuf<int32_t> link_blk;
+    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
+    DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
+    PinnedBuf<double> pin, pin_ne, pin_tr;  // host staging of every per-step D2H result (one stream sync per stage)
+    PinnedBuf<int32_t> pin_i;
+    // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
+    // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
+    // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches
+    // travels through memory the graph's own copy nodes read at execution time: [radius, init_scale] and the shared step
+    // in pinned host buffers.  Values baked into kernel arguments (huber, constrained, fp32 mode) key the graph.
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        double huber = 0.0;
+        int constrained = -1, scalar = -1;
+        int uses = 0;  // plain launches of this stage with the current key so far
+        ~GraphSlot() { if (exec) (void)hipGraphExecDestroy(exec); }
+    };
+    GraphSlot g_new, g_schur, g_trial;
+    bool graphs_ok = true;
+    int graph_after = 200;// capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
+                          // than a solve, so a stage runs as plain launches until it has been used this many times with
+                          // the same key — i.e. on handles that are solved again and again (CBA_LM_GRAPH=<n>, 1 = at once, 0 = never)
+    DevBuf<double> lmp;          // device [radius, init_scale]
+    PinnedBuf<double> pin_lmp, pin_delta;
+    // resident LM (resident_lm.hip): per-camera block lists, the masks of the current options, reduced-system scratch
+    int resident_mode = 1;             // 0 never, 1 when the problem is small (default), 2 whenever the kernel can run it
+    int64_t resident_max_obs = 8192;   // "small": at most this many observations; set per chain in init_lm_state from the
+                                       // measured crossover with the host-driven iteration (CBA_LM_RESIDENT_MAX_OBS overrides)
+    DevBuf<int64_t> cam_off;
+    DevBuf<int8_t> res_active, res_cam_var;
+    DevBuf<double> res_Hcc, res_Ssch, res_out;
+    PinnedBuf<double> pin_res;
+    PinnedBuf<int8_t> pin_mask;
+};
+
+
+inline HipLMState* lm_state(Engine& e) { return reinterpret_cast<HipLMState*>(e.lm_state); }
+
+// resident_lm.hip: the whole LM in one single-workgroup kernel, for problems too small to fill the chip
+bool resident_lm_eligible(const Engine& e, const cba_options& o);
+void resident_lm_warm(Engine& e);
+void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters = false);
+
+}  // namespace cba

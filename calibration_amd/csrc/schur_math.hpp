@@ -32,6 +32,7 @@ CBA_HD double lm_diag(double hii, double scale2, double radius) {
 }
 
 // in-place lower Cholesky of a 6x6 (row-major full storage); false if not positive definite
+// (fp64 division is ~40 dependent instructions on the GPU: one reciprocal per pivot, multiplied through)
 CBA_HD bool chol6(double* A) {
     for (int j = 0; j < 6; ++j) {
         double d = A[j * 6 + j];
@@ -39,13 +40,22 @@ CBA_HD bool chol6(double* A) {
         if (!(d > 0.0)) return false;
         d = sqrt(d);
         A[j * 6 + j] = d;
+        const double r = 1.0 / d;
         for (int i = j + 1; i < 6; ++i) {
             double s = A[i * 6 + j];
             for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
-            A[i * 6 + j] = s / d;
+            A[i * 6 + j] = s * r;
         }
     }
     return true;
+}
+// b <- L^-1 b with the reciprocal diagonal rd[i] = 1 / L[i][i] supplied (many right-hand sides per factor)
+CBA_HD void fwd6r(const double* L, const double* rd, double* b) {
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * b[k];
+        b[i] = s * rd[i];
+    }
 }
 CBA_HD void fwd6(const double* L, double* b) {  // b <- L^-1 b
     for (int i = 0; i < 6; ++i) {
@@ -78,18 +88,19 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
         *gmax = 0.0;
         return true;
     }
-    double H[36];
+    double H[36], gl[6];
     for (int i = 0; i < 36; ++i) H[i] = 0.0;
-    for (int i = 0; i < 6; ++i) gp[i] = 0.0;
+    for (int i = 0; i < 6; ++i) gl[i] = 0.0;
     for (int k = 0; k < nb; ++k) {
         const int b = blks[k];
         const double w = blk_w[b];
         const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
         for (int i = 0; i < 6; ++i) {
             for (int j = i; j < 6; ++j) H[i * 6 + j] += w * acc[hidx(d.PL, i, j)];
-            gp[i] += w * acc[d.NH + i];
+            gl[i] += w * acc[d.NH + i];
         }
     }
+    for (int i = 0; i < 6; ++i) gp[i] = gl[i];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < i; ++j) H[i * 6 + j] = H[j * 6 + i];
     if (init_scale)
@@ -98,24 +109,26 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
     // or of Plus(x, -g) - x when the problem is bounds-constrained)
     double gm = 0.0;
     if (!constrained) {
-        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gp[i]));
+        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
     } else {
-        const double ng[3] = {-gp[0], -gp[1], -gp[2]};
+        const double ng[3] = {-gl[0], -gl[1], -gl[2]};
         double qn[4];
         quat_plus(xview7, ng, qn);
         for (int i = 0; i < 4; ++i) gm = fmax(gm, fabs(qn[i] - xview7[i]));
-        for (int i = 3; i < 6; ++i) gm = fmax(gm, fabs(gp[i]));
+        for (int i = 3; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
     }
     *gmax = gm;
     for (int i = 0; i < 6; ++i) {
         D[i] = lm_diag(H[i * 6 + i], scale2[i], radius);
         H[i * 6 + i] += D[i];
     }
-    const bool ok = chol6(H);
+    const bool ok = chol6(H);  // H now holds the factor: every substitution below reads this local copy, not L
     for (int i = 0; i < 36; ++i) L[i] = H[i];
-    for (int i = 0; i < 6; ++i) y[i] = gp[i];
+    double yl[6], rd[6];
+    for (int i = 0; i < 6; ++i) { yl[i] = gl[i]; rd[i] = 1.0 / H[i * 6 + i]; }
+    if (ok) fwd6r(H, rd, yl);
+    for (int i = 0; i < 6; ++i) y[i] = yl[i];
     if (!ok) return false;
-    fwd6(L, y);
     for (int k = 0; k < nb; ++k) {
         const int b = blks[k];
         const double w = blk_w[b];
@@ -124,7 +137,7 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
         for (int c = 0; c < d.PSH; ++c) {
             double e[6];
             for (int i = 0; i < 6; ++i) e[i] = w * acc[hidx(d.PL, i, 6 + c)];
-            fwd6(L, e);
+            fwd6r(H, rd, e);
             for (int i = 0; i < 6; ++i) Z[i * d.PSH + c] = e[i];
         }
     }
@@ -172,6 +185,14 @@ CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, c
     out4[0] = s2;
     out4[2] = gd;
     out4[3] = rr - dDd - 2.0 * ra;
+}
+
+// Z of view v at global shared column g, row k (0 if the view has no block on that column's camera)
+CBA_HD double z_entry(const SchurDims& d, const int32_t* view_cam_blk, const double* blk_Z, int v, int g, int k, int nsh) {
+    if (g >= nsh) return 0.0;
+    const int cam = g / d.PC, lc = g - cam * d.PC;
+    const int b = view_cam_blk[static_cast<long long>(v) * d.n_cams + cam];
+    return b < 0 ? 0.0 : blk_Z[(static_cast<long long>(b) * 6 + k) * d.PSH + lc];
 }
 
 }  // namespace cba

@@ -375,6 +375,11 @@ class ReprojHandle:
         capi.check(self.lib, self.lib.cba_reproj_block_normal_eq(self.h, dptr(out)))
         return out
 
+    def set_lm_mode(self, mode: int):
+        """0 = host-driven LM iteration, 1 = automatic (default), 2 = the resident single-launch kernel whenever it can
+        take the problem (cba_reproj_set_lm_mode)."""
+        capi.check(self.lib, self.lib.cba_reproj_set_lm_mode(self.h, int(mode)))
+
     def solve(self, opts: CbaOptions) -> CbaSummary:
         s = CbaSummary()
         capi.check(self.lib, self.lib.cba_reproj_solve(self.h, C.byref(opts), C.byref(s)))

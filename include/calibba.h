@@ -203,6 +203,15 @@ int64_t cba_reproj_block_normal_eq_size(const cba_reproj* h); /* doubles per blo
 /* Levenberg-Marquardt solve (what solve_problem + ceres::Solve do, ceresutils.h:27-43). */
 cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary* summary);
 
+/* How cba_reproj_solve runs the iteration.  0: host-driven (every stage a kernel launch, the accept / reject loop on the host;
+ * the only form for multi-rank handles, verbose solves and the fp32 study).  2: "resident" — the whole solve in ONE launch of a
+ * single-workgroup kernel, for problems too small to fill the chip (the sizes the reference's own tests and pipelines run:
+ * the host-driven iteration costs ~0.2 ms per LM step however little work it carries); falls back to 0 when the kernel cannot
+ * take the problem (reduced system wider than 80, > 16 cameras).  1 (default): resident below the measured crossover with
+ * the host-driven form (8192 observations for the intrinsic chain, 2048 extrinsic, 1024 bundle).
+ * Both forms follow the same rules and agree to rounding. */
+cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
+
 /* Covariance in the reference's layout (ceresutils.h:69-126): dense symmetric, AMBIENT block
  * sizes, block order = get_param_blocks() of the stage (intrinsics.cpp:34-50,
  * extrinsics.cpp:50-67, bundle.cpp:48-68).  Returns CBA_ERR_RUNTIME if rank deficient (the

@@ -11,6 +11,7 @@ Tolerances (fp64):
                        1e-6 for the Scheimpflug model, whose tau/principal-point near-degeneracy
                        (condition number ~1e8) amplifies rounding between two correct solvers.
 """
+import copy
 import ctypes as C
 
 import numpy as np
@@ -21,6 +22,15 @@ from tests import helpers
 from tests.helpers import options
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["host", "resident"])
+def lm_mode(request, monkeypatch):
+    """Every test of this module runs twice: with the host-driven LM iteration (backend_hip.hip + lm_core.hpp) and with the
+    resident single-launch kernel (resident_lm.hip) wherever that kernel can take the problem.  The handle reads the
+    variable when it is created."""
+    monkeypatch.setenv("CBA_LM_RESIDENT", "0" if request.param == "host" else "2")
+    return request.param
 
 SCENES = {
     "intr": lambda m, **k: synth.scene_intrinsics(7, model=m, **k),
@@ -428,7 +438,7 @@ def test_single_rank_transports_reproduce_the_plain_solve(gpu_lib):
             s = h.solve(o)
         return sc.flat, s
 
-    f0, s0 = run(lambda h: None)
+    f0, s0 = run(lambda h: h.set_lm_mode(0))  # the all-reduce lives in the host-driven iteration: compare like with like
     f1, s1 = run(lambda h: h.init_rccl(optim.rccl_unique_id(), 1, 0))
     calls = []
 
@@ -843,3 +853,54 @@ def test_plain_c_example_runs(gpu_lib, tmp_path):
     vals = dict(zip(("fx", "fy", "cx", "cy"), [float(t) for t in r.stdout.split("fx")[1].replace("fy", " ").replace("cx", " ").replace("cy", " ").split("(")[0].split()]))
     assert abs(vals["fx"] - 1000) < 1e-5 and abs(vals["fy"] - 1005) < 1e-5 and abs(vals["cx"] - 640) < 1e-5 and abs(vals["cy"] - 360) < 1e-5
     assert "success 1" in r.stdout
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("kind", ["intr", "ext", "bundle"])
+def test_resident_kernel_agrees_with_host_driven_iteration(gpu_lib, kind, model, lm_mode):
+    """The same solve through cba_reproj_set_lm_mode 0 and 2: identical decisions (termination, iteration and accepted-step
+    counts), parameters equal to rounding, and the resident solve bitwise reproducible."""
+    if lm_mode == "host":
+        pytest.skip("compares both forms itself")
+    sc = SCENES[kind](model, noise_px=0.3)
+    _perturb_intr(sc)
+    o = options(epsilon=1e-10, optimize_intrinsics=1)
+    runs = {}
+    for mode in (0, 2, 2):
+        f = copy.deepcopy(sc.flat)
+        with optim.ReprojHandle(f) as h:
+            h.set_lm_mode(mode)
+            s = h.solve(o)
+            cov = h.covariance_shared(o)
+        runs.setdefault(mode, []).append((s, f, cov))
+    (s0, f0, c0), = runs[0]
+    (s1, f1, c1), (s2, f2, c2) = runs[2]
+    assert b"resident kernel" in bytes(s1.report) and b"resident" not in bytes(s0.report)
+    assert (s1.termination, s1.iterations, s1.successful_steps) == (s0.termination, s0.iterations, s0.successful_steps)
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-12 * abs(s0.final_cost)
+    assert abs(s1.initial_cost - s0.initial_cost) <= 1e-13 * abs(s0.initial_cost)
+    tol = 1e-8 if model == 0 else 1e-7  # summation order only, amplified by the conditioning of k3 / tau
+    for name in ("intr", "cam_pose", "view_pose", "target_pose"):
+        a, b = getattr(f0, name), getattr(f1, name)
+        if a is None:
+            continue
+        assert (np.abs(a - b) / np.maximum(1.0, np.abs(a))).max() <= tol, name
+        assert np.array_equal(b, getattr(f2, name)), name
+    assert s2.final_cost == s1.final_cost and s2.iterations == s1.iterations
+    assert np.abs(c1 - c0).max() <= 1e-6 * np.abs(c0).max()
+
+
+def test_resident_kernel_is_the_default_for_small_problems_only(gpu_lib, monkeypatch):
+    monkeypatch.delenv("CBA_LM_RESIDENT", raising=False)
+    small = synth.scene_intrinsics(7, noise_px=0.2)
+    _perturb_intr(small)
+    with optim.ReprojHandle(small.flat) as h:
+        assert b"resident kernel" in bytes(h.solve(options()).report)
+    big = synth.scene_intrinsics(7, rows=40, cols=40, noise_px=0.2)  # 11 200 observations > 8192
+    _perturb_intr(big)
+    with optim.ReprojHandle(big.flat) as h:
+        assert b"resident" not in bytes(h.solve(options()).report)
+        h.set_lm_mode(2)
+        _perturb_intr(big)
+        h.set_params()
+        assert b"resident kernel" in bytes(h.solve(options()).report)

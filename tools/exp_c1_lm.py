@@ -11,4 +11,6 @@ with optim.ReprojHandle(sc.flat) as h:
     for k in range(3):
         h.set_params(intr=init[0], view_pose=init[1])
         t0 = time.perf_counter(); s = h.solve(o); dt = time.perf_counter() - t0
-        print(f"CBA_LM_GRAPH={os.environ.get('CBA_LM_GRAPH', 'default')} solve {k}: {dt*1e3:.2f} ms, {s.iterations} iterations, {dt/s.iterations*1e6:.0f} us/iteration")
+        print(f"CBA_LM_GRAPH={os.environ.get('CBA_LM_GRAPH', 'default')} CBA_LM_RESIDENT={os.environ.get('CBA_LM_RESIDENT', 'default')} solve {k}: "
+              f"{dt*1e3:.2f} ms ({s.solve_seconds*1e3:.2f} in the engine), {s.iterations} iterations, {dt/s.iterations*1e6:.0f} us/iteration, "
+              f"cost {s.final_cost:.9e}, {bytes(s.report).split(b':')[0].decode()}")
