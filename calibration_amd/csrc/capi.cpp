@@ -53,11 +53,13 @@ static int device_count() {
 }
 
 Engine::~Engine() {
+    // the buffers below go back to the process-wide cache (engine.hpp): nothing may still be running on them
+    if (stream) (void)hipStreamSynchronize(stream);
     rccl_destroy(*this);
     destroy_lm_state(*this);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) cache_stream_release(device, stream);
 }
 
 static Engine* as_engine(cba_reproj* h) {
@@ -193,7 +195,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
     e.device = device;
     CBA_HIP(hipSetDevice(device));
-    CBA_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    e.stream = cache_stream();
     CBA_HIP(hipEventCreate(&e.ev0));
     CBA_HIP(hipEventCreate(&e.ev1));
 
@@ -328,6 +330,7 @@ extern "C" {
 const char* cba_version(void) { return CBA_VERSION_STRING; }
 const char* cba_last_error(void) { return g_err.c_str(); }
 int32_t cba_device_count(void) { return device_count(); }
+void cba_trim_cache(void) { try { cache_trim(); } catch (...) {} }
 
 void cba_options_default(cba_options* o) {
     std::memset(o, 0, sizeof(*o));
@@ -684,9 +687,12 @@ cba_status cba_reproj_init_rccl(cba_reproj* h, const uint8_t id[CBA_RCCL_UNIQUE_
 // ---- one-shot entry points -----------------------------------------------------------------------
 static void one_shot(const cba_reproj_problem& d, const cba_options* opts, cba_summary* summary, double* cov) {
     if (!opts || !summary) throw std::invalid_argument("null argument");
+    PhaseTimer pt;
     auto e = std::make_unique<Engine>();
     build_engine(d, 0, *e);
+    pt.lap("one-shot: handle");
     solve_lm(*e, *opts, summary);
+    pt.lap("one-shot: solve");
     if (d.intr) std::memcpy(d.intr, e->h_intr.data(), sizeof(double) * e->h_intr.size());
     if (d.cam_pose && d.chain != CBA_CHAIN_INTRINSIC) std::memcpy(d.cam_pose, e->h_cam.data(), sizeof(double) * e->h_cam.size());
     if (d.view_pose && !e->h_view.empty()) std::memcpy(d.view_pose, e->h_view.data(), sizeof(double) * e->h_view.size());
@@ -702,6 +708,9 @@ static void one_shot(const cba_reproj_problem& d, const cba_options* opts, cba_s
         }
     }
     CBA_HIP(hipStreamSynchronize(e->stream));
+    pt.lap("one-shot: covariance");
+    e.reset();
+    pt.lap("one-shot: release");
 }
 
 cba_status cba_optimize_intrinsics(int32_t camera_model, int32_t n_views, const int64_t* view_offset, const double* X,

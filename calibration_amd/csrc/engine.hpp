@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -45,22 +46,42 @@ struct NoDevice : std::runtime_error {
                                 std::to_string(__LINE__) + ")");                                           \
     } while (0)
 
+// Process-wide cache of device / page-locked blocks and of streams (block_cache.cpp).  The reference's pipeline calls the
+// one-shot entry points stage after stage; a handle is ~70 hipMalloc + ~10 hipHostMalloc, and giving them back cost 1.9 ms
+// of a 5 ms C1-sized call (hipFree synchronises the device).  Released blocks up to 16 MiB are kept (at most 256 MiB per
+// kind and device) in power-of-two size classes and handed to the next handle; cba_trim_cache() frees them.
+void* cache_alloc(bool pinned, size_t bytes, size_t* granted);  // current device; throws HipError
+void cache_release(bool pinned, int device, void* p, size_t granted) noexcept;
+hipStream_t cache_stream();                                     // an idle non-blocking stream of the current device
+void cache_stream_release(int device, hipStream_t s) noexcept;  // the caller has synchronised it
+void cache_trim();
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t granted = 0;  // bytes of the underlying block
+    int device = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
+    // A cached block may be handed to another handle at once: nothing may still be running on it.  Normal paths have
+    // synchronised their stream before buffers go out of scope; unwinding from an exception and replacing a live buffer
+    // have not, so those wait for the device.
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
+        if (p) {
+            if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
+            cache_release(false, device, p, granted);
+        }
+        p = nullptr; n = 0; granted = 0;
     }
     void alloc(size_t count) {
+        if (p) (void)hipDeviceSynchronize();
         release();
         if (count == 0) count = 1;
-        CBA_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        CBA_HIP(hipGetDevice(&device));
+        p = static_cast<T*>(cache_alloc(false, count * sizeof(T), &granted));
         n = count;
     }
     void upload(const T* src, size_t count, hipStream_t s) {
@@ -78,17 +99,40 @@ template <typename T>
 struct PinnedBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t granted = 0;
+    int device = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf&) = delete;
     PinnedBuf& operator=(const PinnedBuf&) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    ~PinnedBuf() { if (p) cache_release(true, device, p, granted); }
     void reserve(size_t count) {
         if (count <= n) return;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; n = 0;
-        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault));
+        if (p) cache_release(true, device, p, granted);
+        p = nullptr; n = 0; granted = 0;
+        CBA_HIP(hipGetDevice(&device));
+        p = static_cast<T*>(cache_alloc(true, count * sizeof(T), &granted));
         n = count;
     }
+};
+
+// An idle non-blocking stream of the current device, leased from the process-wide pool; synchronised and returned on scope
+// exit.  Declare it BEFORE the buffers that are used on it (members are released in reverse order).
+struct StreamLease {
+    hipStream_t s = nullptr;
+    int device = 0;
+    StreamLease() {
+        CBA_HIP(hipGetDevice(&device));
+        s = cache_stream();
+    }
+    StreamLease(const StreamLease&) = delete;
+    StreamLease& operator=(const StreamLease&) = delete;
+    ~StreamLease() {
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            cache_stream_release(device, s);
+        }
+    }
+    operator hipStream_t() const { return s; }
 };
 
 struct Tile {          // 32 bytes, read with scalar loads (wave-uniform)

@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256) void k_axxb_chunk_sum(int64_t n_rows, int64_t 
 namespace {
 struct HipAxxb final : AxxbEval {
     int n;
-    hipStream_t stream = nullptr;
+    StreamLease lease;  // before the buffers: released after them
+    hipStream_t stream = lease;
     DevBuf<double> poses, X, partial, partial2, out;
     int64_t n_rows = 0, n_chunks = 0;
     dim3 grid;
     HipAxxb(int n_poses, const double* bTg, const double* cTt) : n(n_poses) {
-        CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         std::vector<double> h(static_cast<size_t>(n) * 24);
         for (int k = 0; k < n; ++k) {
             // R from the (unit) quaternion exactly as Eigen::Isometry3d stored it before populate_quat_tran
@@ -100,7 +100,7 @@ struct HipAxxb final : AxxbEval {
         partial2.alloc(static_cast<size_t>(n_chunks) * AXXB_NACC);
         CBA_HIP(hipStreamSynchronize(stream));
     }
-    ~HipAxxb() override { if (stream) (void)hipStreamDestroy(stream); }
+    ~HipAxxb() override { (void)hipStreamSynchronize(stream); }
     void eval(const double* pose7, double huber_delta, double* acc) override {
         double hx[12];
         quat_to_rotmat(pose7, hx);  // un-normalised, as quat_array_to_rotmat (observationutils.h:20-24)

@@ -44,9 +44,9 @@ void homography_batch(int n_views, const int64_t* view_offset, const double* X, 
         if (n > 0x7fffffff) throw std::invalid_argument("view too large");
     }
     CBA_HIP(hipSetDevice(device));
-    hipStream_t stream;
-    CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    try {
+    StreamLease lease;
+    const hipStream_t stream = lease;
+    {
         const int64_t n_obs = view_offset[n_views];
         DevBuf<double> dX, dY, du, dv;
         DevBuf<int64_t> doff;
@@ -82,11 +82,7 @@ void homography_batch(int n_views, const int64_t* view_offset, const double* X, 
                               i, n_views, r.termination, r.iterations, r.initial_cost, r.final_cost);
             }
         }
-    } catch (...) {
-        (void)hipStreamDestroy(stream);
-        throw;
     }
-    (void)hipStreamDestroy(stream);
 }
 
 }  // namespace cba

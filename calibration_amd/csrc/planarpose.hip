@@ -43,9 +43,9 @@ void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X,
     if (num_radial < 0 || num_radial + 2 > VP_MAX_M) throw std::invalid_argument("num_radial must be in [0, 3]");
     if (!view_offset || !X || !Y || !u || !v || !kmtx5 || !pose7 || !o) throw std::invalid_argument("null argument");
     CBA_HIP(hipSetDevice(device));
-    hipStream_t stream;
-    CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    try {
+    StreamLease lease;
+    const hipStream_t stream = lease;
+    {
         const int64_t n_obs = view_offset[n_views];
         DevBuf<double> dX, dY, du, dv, dK;
         DevBuf<int64_t> doff;
@@ -99,11 +99,7 @@ void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X,
                               i, n_views, r.termination, r.iterations, r.initial_cost, r.final_cost);
             }
         }
-    } catch (...) {
-        (void)hipStreamDestroy(stream);
-        throw;
     }
-    (void)hipStreamDestroy(stream);
 }
 
 }  // namespace cba

@@ -42,9 +42,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void k_dlt_homography(int n_views,
 void dlt_homography_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                           double* H9, int32_t* ok, int device) {
     CBA_HIP(hipSetDevice(device));
-    hipStream_t stream;
-    CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    try {
+    StreamLease lease;
+    const hipStream_t stream = lease;
+    {
         const int64_t n_obs = view_offset[n_views];
         DevBuf<double> dX, dY, du, dv, dH;
         DevBuf<int64_t> doff;
@@ -60,19 +60,15 @@ void dlt_homography_batch(int n_views, const int64_t* view_offset, const double*
         dH.download(H9, 9 * static_cast<size_t>(n_views), stream);
         dok.download(ok, n_views, stream);
         CBA_HIP(hipStreamSynchronize(stream));
-    } catch (...) {
-        (void)hipStreamDestroy(stream);
-        throw;
     }
-    (void)hipStreamDestroy(stream);
 }
 
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, double* pose7, int device) {
     CBA_HIP(hipSetDevice(device));
-    hipStream_t stream;
-    CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    try {
+    StreamLease lease;
+    const hipStream_t stream = lease;
+    {
         const int64_t n_obs = view_offset[n_views];
         DevBuf<double> dX, dY, du, dv, dK, dP;
         DevBuf<int64_t> doff;
@@ -86,11 +82,7 @@ void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X,
         CBA_HIP(hipGetLastError());
         dP.download(pose7, 7 * static_cast<size_t>(n_views), stream);
         CBA_HIP(hipStreamSynchronize(stream));
-    } catch (...) {
-        (void)hipStreamDestroy(stream);
-        throw;
     }
-    (void)hipStreamDestroy(stream);
 }
 
 }  // namespace cba

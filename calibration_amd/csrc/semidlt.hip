@@ -102,13 +102,13 @@ __global__ __launch_bounds__(64 * SD_WAVES) void k_sd_resid(int n_views, const i
 
 namespace {
 struct HipSemiDlt final : SemiDltEval {
-    hipStream_t stream = nullptr;
+    StreamLease lease;  // before the buffers: released after them
+    hipStream_t stream = lease;
     DevBuf<double> X, Y, u, v, kappa, poses, out1, sums, out2, alpha, sview;
     DevBuf<int64_t> off;
     dim3 grid, block;
     HipSemiDlt(int n_views, const int64_t* view_offset, const double* hX, const double* hY, const double* hu, const double* hv, int num_radial) {
         V = n_views; nr = num_radial; n_obs = view_offset[n_views];
-        CBA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         const size_t n = static_cast<size_t>(std::max<int64_t>(n_obs, 1));
         X.alloc(n); Y.alloc(n); u.alloc(n); v.alloc(n);
         X.upload(hX, n_obs, stream); Y.upload(hY, n_obs, stream); u.upload(hu, n_obs, stream); v.upload(hv, n_obs, stream);
@@ -119,7 +119,7 @@ struct HipSemiDlt final : SemiDltEval {
         grid = dim3((V + SD_WAVES - 1) / SD_WAVES); block = dim3(64 * SD_WAVES);
         CBA_HIP(hipStreamSynchronize(stream));
     }
-    ~HipSemiDlt() override { if (stream) (void)hipStreamDestroy(stream); }
+    ~HipSemiDlt() override { (void)hipStreamSynchronize(stream); }
     void put(const double* kappa5, const double* poses7) {
         kappa.upload(kappa5, 5, stream);
         poses.upload(poses7, 7 * static_cast<size_t>(V), stream);

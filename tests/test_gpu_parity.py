@@ -904,3 +904,26 @@ def test_resident_kernel_is_the_default_for_small_problems_only(gpu_lib, monkeyp
         _perturb_intr(big)
         h.set_params()
         assert b"resident kernel" in bytes(h.solve(options()).report)
+
+
+def test_block_cache_reuse_leaves_results_unchanged(gpu_lib):
+    """Handles return their device / pinned blocks and their stream to a process-wide cache (block_cache.cpp).  A solve on
+    recycled blocks (which hold another problem's stale data) must equal the solve on fresh ones bit for bit."""
+    def run(n_views, seed):
+        sc = synth.scene_intrinsics(n_views, noise_px=0.2, seed=seed)
+        with optim.ReprojHandle(sc.flat) as h:
+            s = h.solve(options())
+            cov = h.covariance_shared(options())
+        return sc.flat.intr.copy(), sc.flat.view_pose.copy(), s.final_cost, s.iterations, cov
+
+    gpu_lib.cba_trim_cache()
+    fresh = run(9, 3)
+    run(14, 4)          # different sizes: other size classes enter the cache
+    run(9, 5)           # same sizes, different data: the blocks `fresh` used now hold this problem's state
+    again = run(9, 3)
+    for a, b in zip(fresh, again):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    gpu_lib.cba_trim_cache()
+    after_trim = run(9, 3)
+    for a, b in zip(fresh, after_trim):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
