@@ -178,6 +178,31 @@ def main():
         lm_hung = th.is_alive()
         lm = {"error": f"LM solve did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else lm_box.get("lm")
 
+    # ---- BASELINE.json configs[0] (20 views x 88 points, the reference's own test size), rank 0 only: the whole LM as one
+    # resident single-workgroup kernel launch (resident_lm.hip) and the complete call the reference's pipeline makes
+    lm_c1 = None
+    if rank == 0 and not args.no_lm and not lm_hung:
+        try:
+            from calibration_amd.geometry import pose_to_matrix
+
+            sc1 = synth.scene_intrinsics(20, noise_px=0.2)
+            f1 = sc1.flat
+            views1 = [np.c_[f1.X[a:b], f1.Y[a:b], f1.u[a:b], f1.v[a:b]] for a, b in zip(f1.blk_offset[:-1], f1.blk_offset[1:])]
+            poses1 = [pose_to_matrix(p) for p in f1.view_pose]
+            best = None
+            for _ in range(4):
+                t1 = time.perf_counter()
+                r1 = optim.optimize_intrinsics(views1, f1.intr.reshape(-1).copy(), poses1)
+                dt = time.perf_counter() - t1
+                if best is None or dt < best[0]:
+                    best = (dt, r1)
+            lm_c1 = {"workload": "pinhole intrinsics, 20 views x 88 pts (configs[0])", "call_s": best[0],
+                     "solve_s": float(best[1].core.solve_seconds), "iterations": int(best[1].core.iterations),
+                     "success": bool(best[1].core.success), "call": "handle + LM + 150x150 covariance + release, best of 4",
+                     "report": best[1].core.report}
+        except Exception as ex:
+            lm_c1 = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- CPU baseline: the oracle's autodiff evaluation on a bounded sample, rank 0 only --------------
     cpu = None
     if rank == 0 and not args.no_cpu:
@@ -221,6 +246,7 @@ def main():
             "cpu_baseline": cpu,
             "mode_b": mode_b,
             "lm": lm,
+            "lm_c1": lm_c1,
             "scene_gen_s": t_gen,
         }
         print(json.dumps(out), flush=True)

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "cba_pose_from_matrix": (None, [c_double_p, c_double_p]),
     "cba_pose_to_matrix": (None, [c_double_p, c_double_p]),
     "cba_reproj_create": (C.c_int32, [C.POINTER(CbaReprojProblem), C.c_int32, C.POINTER(C.c_void_p)]),
+    "cba_reproj_create_aos": (C.c_int32, [C.POINTER(CbaReprojProblem), C.POINTER(c_double_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "cba_reproj_destroy": (None, [C.c_void_p]),
     "cba_reproj_set_params": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cba_reproj_get_params": (C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),

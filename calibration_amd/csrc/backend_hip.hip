@@ -498,10 +498,10 @@ void destroy_lm_state(Engine& e) {
     e.lm_state = nullptr;
 }
 
-void init_lm_state(Engine& e, const cba_reproj_problem& d) {
+void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     auto* st = new HipLMState();
     e.lm_state = st;
-    build_structure(d, st->s);
+    build_structure(d, st->s, have_records);
     const Structure& s = st->s;
     st->dims = SchurDims{s.PL, s.NH, s.NACC, s.PSH, s.PC, s.n_cams, s.chain};
     st->n_vchunks = std::max(1, (s.n_views + VCHUNK - 1) / VCHUNK);

@@ -122,14 +122,19 @@ struct StagedUpload {
         const size_t c = static_cast<size_t>(std::min<int64_t>(CHUNK, longest));
         pin[0].reserve(c); pin[1].reserve(c);
     }
+    // source_of(b)[i * stride] = element i of block b (stride 1: SoA input; 4: interleaved {X, Y, u, v} records)
+    static void gather(double* dst, const double* src, int64_t n, int64_t stride) {
+        if (stride == 1) { std::memcpy(dst, src, sizeof(double) * static_cast<size_t>(n)); return; }
+        for (int64_t i = 0; i < n; ++i) dst[i] = src[i * stride];
+    }
     template <class Off, class Len, class Src>
-    void run(double* dst, int64_t len, int n_blocks, Off&& offset_of, Len&& length_of, Src&& source_of) {
+    void run(double* dst, int64_t len, int n_blocks, Off&& offset_of, Len&& length_of, Src&& source_of, int64_t stride = 1) {
         // blocks in increasing destination order (offsets are monotone in b for the blocks that are stored)
         std::vector<int> order;
         for (int b = 0; b < n_blocks; ++b) if (offset_of(b) >= 0) order.push_back(b);
         if (!pin[0].p) {
             small.assign(static_cast<size_t>(len), 0.0);
-            for (int b : order) std::memcpy(&small[static_cast<size_t>(offset_of(b))], source_of(b), sizeof(double) * static_cast<size_t>(length_of(b)));
+            for (int b : order) gather(&small[static_cast<size_t>(offset_of(b))], source_of(b), length_of(b), stride);
             CBA_HIP(hipMemcpyAsync(dst, small.data(), sizeof(double) * static_cast<size_t>(len), hipMemcpyHostToDevice, stream));
             CBA_HIP(hipStreamSynchronize(stream));
             return;
@@ -150,7 +155,7 @@ struct StagedUpload {
                 const int b = order[first + i];
                 const int64_t o = offset_of(b), n = length_of(b);
                 const int64_t lo = std::max(o, c0), hi = std::min(o + n, c1);
-                if (hi > lo) std::memcpy(buf + (lo - c0), source_of(b) + (lo - o), sizeof(double) * static_cast<size_t>(hi - lo));
+                if (hi > lo) gather(buf + (lo - c0), source_of(b) + (lo - o) * stride, hi - lo, stride);
             };
             if (c1 - c0 >= (int64_t(1) << 20)) parallel_blocks(nb, copy_block);
             else for (int i = 0; i < nb; ++i) copy_block(i);
@@ -161,12 +166,18 @@ struct StagedUpload {
     }
 };
 
-static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
+// `aos` (optional): aos[b] = block b's observations as interleaved {object_x, object_y, image_u, image_v} records — the
+// memory of the reference's std::vector<PlanarObservation> (include/calib/estimation/linear/planarpose.h:22-26) — read in
+// place; d.X, d.Y, d.u, d.v are then ignored.  SURVEY.md §8(f) rank 4: no AoS -> SoA copy at the caller.
+static void build_engine(const cba_reproj_problem& d, int device, Engine& e, const double* const* aos = nullptr) {
     PhaseTimer pt;
     if (const char* ev = getenv("CBA_EVAL_VARIANT")) e.eval_variant = atoi(ev);
     if (const char* eb = getenv("CBA_EVAL_BLOCKED")) e.eval_blocked = atoi(eb);
     Structure st;
-    build_structure(d, st);  // validation mirroring the reference (SURVEY.md §8b "Errors")
+    if (aos)
+        for (int b = 0; b < d.n_blocks; ++b)
+            if (!aos[b]) throw std::invalid_argument("missing observation records of a block");
+    build_structure(d, st, aos != nullptr);  // validation mirroring the reference (SURVEY.md §8b "Errors")
     e.chain = st.chain; e.model = st.model;
     e.PI = st.PI; e.PL = st.PL; e.NACC = st.NACC;
     e.n_blocks = st.n_blocks; e.n_cams = st.n_cams; e.n_views = st.n_views;
@@ -205,14 +216,27 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
         // residual blocks whose (X, Y) lists are bitwise identical share one device copy.  Hashing and the byte-for-byte
         // confirmation run on a few host threads (at C3 this is 2.6 GB of target points: 0.4 s on one core).
         e.xy_offset.assign(d.n_blocks, 0);
+        const int64_t stride = aos ? 4 : 1;
+        // component c (0 X, 1 Y, 2 u, 3 v) of block b: element i at comp(c, b)[i * stride]
+        auto comp = [&](int c, int b) -> const double* {
+            if (aos) return aos[b] + c;
+            const double* base[4] = {d.X, d.Y, d.u, d.v};
+            return base[c] + e.blk_offset[b];
+        };
+        auto same_bits = [&](const double* p, const double* q, int64_t n) {
+            if (stride == 1) return std::memcmp(p, q, sizeof(double) * static_cast<size_t>(n)) == 0;
+            for (int64_t i = 0; i < n; ++i)
+                if (std::memcmp(p + i * stride, q + i * stride, 8) != 0) return false;
+            return true;
+        };
         std::vector<uint64_t> hashes(d.n_blocks);
         parallel_blocks(d.n_blocks, [&](int b) {
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
             uint64_t hsh = 1469598103934665603ULL ^ static_cast<uint64_t>(n);
-            for (const double* p : {d.X + e.blk_offset[b], d.Y + e.blk_offset[b]})
+            for (const double* p : {comp(0, b), comp(1, b)})
                 for (int64_t i = 0; i < n; ++i) {
                     uint64_t w;
-                    std::memcpy(&w, p + i, 8);
+                    std::memcpy(&w, p + i * stride, 8);
                     hsh = (hsh ^ w) * 1099511628211ULL;
                     hsh ^= hsh >> 29;
                 }
@@ -231,8 +255,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
             const int c = cand[b];
             if (c < 0) return;
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b], nc = e.blk_offset[c + 1] - e.blk_offset[c];
-            same[b] = nc == n && std::memcmp(d.X + e.blk_offset[c], d.X + e.blk_offset[b], sizeof(double) * n) == 0 &&
-                      std::memcmp(d.Y + e.blk_offset[c], d.Y + e.blk_offset[b], sizeof(double) * n) == 0;
+            same[b] = nc == n && same_bits(comp(0, c), comp(0, b), n) && same_bits(comp(1, c), comp(1, b), n);
         });
         std::vector<int> owner(d.n_blocks, -1);
         int64_t xy_pad = 0;
@@ -253,17 +276,13 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
         // padded SoA arrays go up through two page-locked bounce buffers: host threads fill chunk k+1 while chunk k is in flight
         StagedUpload up(e.stream);
         up.reserve(std::max(e.ld, e.ld_xy));
-        for (int a = 0; a < 2; ++a) {
-            const double* src = a == 0 ? d.X : d.Y;
+        for (int a = 0; a < 2; ++a)
             up.run(a == 0 ? e.X.p : e.Y.p, e.ld_xy, d.n_blocks,
                    [&](int b2) { return owner[b2] == b2 ? e.xy_offset[b2] : int64_t(-1); },
-                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return src + e.blk_offset[b2]; });
-        }
-        for (int a = 0; a < 2; ++a) {
-            const double* src = a == 0 ? d.u : d.v;
+                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return comp(a, b2); }, stride);
+        for (int a = 0; a < 2; ++a)
             up.run(a == 0 ? e.u.p : e.v.p, e.ld, d.n_blocks, [&](int b2) { return e.pad_offset[b2]; },
-                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return src + e.blk_offset[b2]; });
-        }
+                   [&](int b2) { return e.blk_offset[b2 + 1] - e.blk_offset[b2]; }, [&](int b2) { return comp(2 + a, b2); }, stride);
     }
     pt.lap("stage + upload X, Y, u, v");
     // ---- tile tables ----------------------------------------------------------------------------
@@ -319,7 +338,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e) {
     e.cost_part.alloc(static_cast<size_t>(2 * ((d.n_blocks + 2047) / 2048 + 1)));  // allocated here: launch_cost may run inside a graph capture
     CBA_HIP(hipStreamSynchronize(e.stream));
     pt.lap("parameters + buffers");
-    init_lm_state(e, d);
+    init_lm_state(e, d, aos != nullptr);
     pt.lap("LM state");
     warm_lm(e);
     pt.lap("warm-up pass");
@@ -399,6 +418,15 @@ cba_status cba_reproj_create(const cba_reproj_problem* desc, int32_t device, cba
         if (!desc || !out) throw std::invalid_argument("null argument");
         auto e = std::make_unique<Engine>();
         build_engine(*desc, device, *e);
+        *out = reinterpret_cast<cba_reproj*>(e.release());
+    });
+}
+
+cba_status cba_reproj_create_aos(const cba_reproj_problem* desc, const double* const* blk_obs, int32_t device, cba_reproj** out) {
+    return guarded([&] {
+        if (!desc || !out || (desc->n_blocks > 0 && !blk_obs)) throw std::invalid_argument("null argument");
+        auto e = std::make_unique<Engine>();
+        build_engine(*desc, device, *e, blk_obs);
         *out = reinterpret_cast<cba_reproj*>(e.release());
     });
 }

@@ -233,7 +233,7 @@ void launch_normal_eq(Engine& e);                       // Mode B: blk_acc[b] = 
 void launch_cost(Engine& e, double huber_delta);        // scalar_out[0] = 1/2 sum rho(blk_s)
 
 // backend_hip.hip
-void init_lm_state(Engine& e, const cba_reproj_problem& d);
+void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records = false);
 void destroy_lm_state(Engine& e);
 void warm_lm(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);

@@ -56,7 +56,8 @@ struct Structure {
     }
 };
 
-inline void build_structure(const cba_reproj_problem& d, Structure& s) {
+// have_records: the observations arrive as per-block {X, Y, u, v} records (cba_reproj_create_aos), not through d.X .. d.v
+inline void build_structure(const cba_reproj_problem& d, Structure& s, bool have_records = false) {
     if (d.chain < 0 || d.chain > 2) throw std::invalid_argument("unknown chain");
     if (d.camera_model < 0 || d.camera_model > 1) throw std::invalid_argument("unknown camera model");
     s.chain = d.chain; s.model = d.camera_model;
@@ -72,7 +73,7 @@ inline void build_structure(const cba_reproj_problem& d, Structure& s) {
     }
     if (d.n_blocks < 0 || d.n_cams <= 0) throw std::invalid_argument("bad problem sizes");
     if (d.chain == CBA_CHAIN_INTRINSIC && d.n_cams != 1) throw std::invalid_argument("intrinsic chain takes exactly one camera");
-    if (d.n_blocks > 0 && (!d.blk_offset || !d.X || !d.Y || !d.u || !d.v)) throw std::invalid_argument("missing observation arrays");
+    if (d.n_blocks > 0 && (!d.blk_offset || (!have_records && (!d.X || !d.Y || !d.u || !d.v)))) throw std::invalid_argument("missing observation arrays");
     if (!d.intr) throw std::invalid_argument("missing intrinsics");
     if (d.chain == CBA_CHAIN_EXTRINSIC && (!d.cam_pose || !d.blk_view || !d.blk_cam)) throw std::invalid_argument("extrinsic: missing arrays");
     if (d.chain != CBA_CHAIN_BUNDLE && d.n_views > 0 && !d.view_pose) throw std::invalid_argument("missing view poses");

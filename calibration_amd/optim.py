@@ -283,12 +283,27 @@ def flatten_bundle(observations: Sequence[BundleObservation], cameras, init_g_se
 class ReprojHandle:
     """RAII wrapper of ``cba_reproj``: observations + parameters resident in HBM."""
 
-    def __init__(self, flat: FlatProblem, device: int = 0, lib=None):
+    def __init__(self, flat: FlatProblem, device: int = 0, lib=None, records: Optional[Sequence[np.ndarray]] = None):
+        """``records`` (optional): one C-contiguous float64 array of shape (n_b, 4) per residual block holding its
+        observations as {object_x, object_y, image_u, image_v} rows — the layout of the reference's
+        ``std::vector<PlanarObservation>`` — handed to ``cba_reproj_create_aos`` and read in place (the flat X, Y, u, v
+        arrays are then not used)."""
         self.lib = lib or capi.load_library()
         self.flat = flat
         self._desc = flat.struct()
         h = C.c_void_p()
-        capi.check(self.lib, self.lib.cba_reproj_create(C.byref(self._desc), int(device), C.byref(h)))
+        if records is None:
+            capi.check(self.lib, self.lib.cba_reproj_create(C.byref(self._desc), int(device), C.byref(h)))
+        else:
+            if len(records) != flat.n_blocks:
+                raise ValueError("one record array per residual block")
+            recs = [np.ascontiguousarray(r, dtype=np.float64).reshape(-1, 4) for r in records]
+            for b, r in enumerate(recs):
+                if r.shape[0] != int(flat.blk_offset[b + 1] - flat.blk_offset[b]):
+                    raise ValueError("record count differs from blk_offset")
+            ptrs = (capi.c_double_p * max(1, len(recs)))(*[capi.dptr(r) for r in recs])
+            self._desc.X = self._desc.Y = self._desc.u = self._desc.v = None
+            capi.check(self.lib, self.lib.cba_reproj_create_aos(C.byref(self._desc), ptrs, int(device), C.byref(h)))
         self.h = h
         self._cb = None
 

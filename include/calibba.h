@@ -166,6 +166,13 @@ void cba_pose_to_matrix(const double* pose7, double* m44_colmajor);
  * bad indices -> INVALID_ARGUMENT), copies observations into padded SoA device arrays and the
  * parameters into device blocks.  Host buffers may be freed after this returns. */
 cba_status cba_reproj_create(const cba_reproj_problem* desc, int32_t device, cba_reproj** out);
+/* The same from array-of-structures input, read in place: blk_obs[b] points to block b's observations as interleaved
+ * {object_x, object_y, image_u, image_v} records (32 bytes each) — exactly the memory of the reference's
+ * std::vector<PlanarObservation> (include/calib/estimation/linear/planarpose.h:22-26: two Eigen::Vector2d), so a binding
+ * passes view.data() and never builds X / Y / u / v arrays (desc->X, Y, u, v are ignored and may be NULL; desc->blk_offset
+ * still gives the record counts).  SURVEY.md §8(f) rank 4: at 1.6e8 observations the caller-side AoS -> SoA copy alone is
+ * 5 GB read + 5 GB written. */
+cba_status cba_reproj_create_aos(const cba_reproj_problem* desc, const double* const* blk_obs, int32_t device, cba_reproj** out);
 void cba_reproj_destroy(cba_reproj* h);
 cba_status cba_reproj_set_params(cba_reproj* h, const double* intr, const double* cam_pose,
                                  const double* view_pose, const double* target_pose);

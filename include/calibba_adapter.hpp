@@ -16,6 +16,7 @@
 //   calib::optimize_homography                             src/estimation/optim/homography.cpp:144-175
 #pragma once
 #include <Eigen/Geometry>
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <iostream>
@@ -68,9 +69,6 @@ inline void fill_core(const cba_summary& s, const cba_options& o, const std::vec
     }
 }
 
-struct Soa {
-    std::vector<double> X, Y, u, v;
-    std::vector<int64_t> off{0};
     std::vector<int32_t> cam, view;
     std::vector<double> bTg;
     void push(const calib::PlanarView& pv, int c, int vw) {
@@ -82,6 +80,38 @@ struct Soa {
         cam.push_back(c); view.push_back(vw);
     }
 };
+
+// The reference's PlanarObservation {Eigen::Vector2d object_xy, image_uv} (linear/planarpose.h:22-26) is four contiguous
+// doubles, so a PlanarView's storage IS the {X, Y, u, v} record array cba_reproj_create_aos reads in place: the three
+// reprojection solvers below never copy an observation on the host.
+static_assert(sizeof(calib::PlanarObservation) == 4 * sizeof(double), "PlanarObservation must be {object_xy, image_uv} = 4 doubles");
+struct Records {
+    std::vector<const double*> obs;
+    std::vector<int64_t> off{0};
+    std::vector<int32_t> cam, view;
+    std::vector<double> bTg;
+    void push(const calib::PlanarView& pv, int c, int vw) {
+        obs.push_back(reinterpret_cast<const double*>(pv.data()));
+        off.push_back(off.back() + static_cast<int64_t>(pv.size()));
+        cam.push_back(c); view.push_back(vw);
+    }
+};
+
+// what the one-shot C entry points do (capi.cpp one_shot), on records: handle, solve, parameters back, covariance, release
+inline void solve_records(cba_reproj_problem& d, const Records& r, const cba_options& o, cba_summary* sum, std::vector<double>& cov) {
+    d.n_blocks = static_cast<int32_t>(r.obs.size());
+    d.blk_offset = r.off.data();
+    cba_reproj* h = nullptr;
+    check(cba_reproj_create_aos(&d, r.obs.data(), 0, &h));
+    struct Release { cba_reproj* h; ~Release() { cba_reproj_destroy(h); } } release{h};
+    check(cba_reproj_solve(h, &o, sum));
+    check(cba_reproj_get_params(h, d.intr, d.cam_pose, d.view_pose, d.target_pose));
+    if (!cov.empty()) {
+        const cba_status st = cba_reproj_covariance(h, &o, cov.data());
+        if (st == CBA_ERR_RUNTIME) std::fill(cov.begin(), cov.end(), 0.0);  // rank deficient: the reference leaves the matrix empty
+        else check(st);
+    }
+}
 
 inline void pose_in(const Eigen::Isometry3d& T, double* p7) { cba_pose_from_matrix(T.data(), p7); }
 inline Eigen::Isometry3d pose_out(const double* p7) {
@@ -97,7 +127,9 @@ auto optimize_intrinsics(const std::vector<calib::PlanarView>& views, const Came
     using Traits = calib::CameraTraits<CameraT>;
     std::array<double, Traits::param_count> intr{};
     Traits::to_array(init_camera, intr);
-    Soa s;
+    if (views.size() < 4)  // intrinsics.cpp:92-96
+        throw std::invalid_argument("Insufficient views for calibration (at least 4 required).");
+    Records s;
     for (size_t i = 0; i < views.size(); ++i) s.push(views[i], 0, static_cast<int>(i));
     std::vector<double> poses(7 * init_c_se3_t.size());
     for (size_t i = 0; i < init_c_se3_t.size(); ++i) pose_in(init_c_se3_t[i], &poses[7 * i]);
@@ -106,9 +138,12 @@ auto optimize_intrinsics(const std::vector<calib::PlanarView>& views, const Came
     cba_summary sum{};
     const Eigen::Index dim = static_cast<Eigen::Index>(Traits::param_count + 7 * views.size());
     std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
-    check(cba_optimize_intrinsics(ModelOf<CameraT>::value, static_cast<int32_t>(views.size()), s.off.data(), s.X.data(),
-                                  s.Y.data(), s.u.data(), s.v.data(), intr.data(), poses.data(), &o, &sum,
-                                  cov.empty() ? nullptr : cov.data()));
+    o.optimize_intrinsics = 1;
+    cba_reproj_problem d{};
+    d.chain = CBA_CHAIN_INTRINSIC; d.camera_model = ModelOf<CameraT>::value;
+    d.n_cams = 1; d.n_views = static_cast<int32_t>(views.size());
+    d.intr = intr.data(); d.view_pose = poses.data();
+    solve_records(d, s, o, &sum, cov);
     calib::IntrinsicsOptimizationResult<CameraT> res;
     res.camera = Traits::template from_array<double>(intr.data());
     res.c_se3_t.resize(views.size());
@@ -134,7 +169,7 @@ auto optimize_extrinsics(const std::vector<calib::MulticamPlanarView>& views, co
         pose_in(init_c_se3_r[c], &cams[7 * c]);
     }
     for (size_t v = 0; v < V; ++v) pose_in(init_r_se3_t[v], &tgts[7 * v]);
-    Soa s;
+    Records s;
     for (size_t v = 0; v < V; ++v)
         for (size_t c = 0; c < C; ++c)
             if (!views[v][c].empty()) s.push(views[v][c], static_cast<int>(c), static_cast<int>(v));  // extrinsics.cpp:94-96
@@ -145,10 +180,12 @@ auto optimize_extrinsics(const std::vector<calib::MulticamPlanarView>& views, co
     cba_summary sum{};
     const Eigen::Index dim = static_cast<Eigen::Index>(C * (P + 7) + 7 * V);
     std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
-    check(cba_optimize_extrinsics(ModelOf<CameraT>::value, static_cast<int32_t>(C), static_cast<int32_t>(V),
-                                  static_cast<int32_t>(s.cam.size()), s.off.data(), s.view.data(), s.cam.data(), s.X.data(),
-                                  s.Y.data(), s.u.data(), s.v.data(), intr.data(), cams.data(), tgts.data(), &o, &sum,
-                                  cov.empty() ? nullptr : cov.data()));
+    cba_reproj_problem d{};
+    d.chain = CBA_CHAIN_EXTRINSIC; d.camera_model = ModelOf<CameraT>::value;
+    d.n_cams = static_cast<int32_t>(C); d.n_views = static_cast<int32_t>(V);
+    d.blk_view = s.view.data(); d.blk_cam = s.cam.data();
+    d.intr = intr.data(); d.cam_pose = cams.data(); d.view_pose = tgts.data();
+    solve_records(d, s, o, &sum, cov);
     calib::ExtrinsicOptimizationResult<CameraT> res;
     res.cameras.resize(C); res.c_se3_r.resize(C); res.r_se3_t.resize(V);
     for (size_t c = 0; c < C; ++c) {
@@ -177,7 +214,7 @@ auto optimize_bundle(const std::vector<calib::BundleObservation>& observations, 
         pose_in(init_g_se3_c[c], &g[7 * c]);
     }
     pose_in(init_b_se3_t, bt.data());
-    Soa s;
+    Records s;
     for (const auto& ob : observations) {
         s.push(ob.view, static_cast<int>(ob.camera_index), 0);
         const Eigen::Matrix3d R = ob.b_se3_g.linear();
@@ -193,9 +230,12 @@ auto optimize_bundle(const std::vector<calib::BundleObservation>& observations, 
     cba_summary sum{};
     const Eigen::Index dim = static_cast<Eigen::Index>(C * (P + 7) + 7);
     std::vector<double> cov(o.compute_covariance ? static_cast<size_t>(dim * dim) : 0);
-    check(cba_optimize_bundle(ModelOf<CameraT>::value, static_cast<int32_t>(C), static_cast<int32_t>(observations.size()),
-                              s.off.data(), s.cam.data(), s.bTg.data(), s.X.data(), s.Y.data(), s.u.data(), s.v.data(),
-                              intr.data(), g.data(), bt.data(), &o, &sum, cov.empty() ? nullptr : cov.data()));
+    cba_reproj_problem d{};
+    d.chain = CBA_CHAIN_BUNDLE; d.camera_model = ModelOf<CameraT>::value;
+    d.n_cams = static_cast<int32_t>(C); d.n_views = 0;
+    d.blk_cam = s.cam.data(); d.blk_b_T_g = s.bTg.data();
+    d.intr = intr.data(); d.cam_pose = g.data(); d.target_pose = bt.data();
+    solve_records(d, s, o, &sum, cov);
     calib::BundleResult<CameraT> res;
     res.cameras.resize(C); res.g_se3_c.resize(C);
     for (size_t c = 0; c < C; ++c) {

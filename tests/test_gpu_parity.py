@@ -927,3 +927,30 @@ def test_block_cache_reuse_leaves_results_unchanged(gpu_lib):
     after_trim = run(9, 3)
     for a, b in zip(fresh, after_trim):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("kind", ["intr", "ext"])
+def test_create_from_observation_records_equals_flat_arrays(gpu_lib, kind):
+    """cba_reproj_create_aos reads {object_xy, image_uv} records in place (the memory of std::vector<PlanarObservation>):
+    same device state as the flat-array creation — Mode A output, de-duplication and LM result bit for bit; ragged blocks,
+    one block with its own target points."""
+    sc = SCENES[kind](0, noise_px=0.3)
+    f = sc.flat
+    lo, hi = int(f.blk_offset[1]), int(f.blk_offset[2])
+    f.X[lo:hi] += 1e-3  # block 1 no longer shares the target point list
+    recs = [np.ascontiguousarray(np.stack([f.X[a:b], f.Y[a:b], f.u[a:b], f.v[a:b]], axis=1))
+            for a, b in zip(f.blk_offset[:-1], f.blk_offset[1:])]
+    _perturb_intr(sc)
+    o = options(epsilon=1e-10, optimize_intrinsics=1)
+    out = []
+    for records in (None, recs):
+        g = copy.deepcopy(f)
+        with optim.ReprojHandle(g, records=records) as h:
+            h.eval()
+            r, J = h.eval_fetch()
+            s = h.solve(o)
+        out.append((r, J, g.intr.copy(), g.view_pose.copy(), s.final_cost, s.iterations))
+    for a, b in zip(*out):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    with pytest.raises(ValueError):
+        optim.ReprojHandle(copy.deepcopy(f), records=recs[:-1] + [np.zeros((0, 4))])  # record count differs from blk_offset
