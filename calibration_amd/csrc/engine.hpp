@@ -147,11 +147,6 @@ constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
 constexpr int OPL_B = 16;    // Mode B/R: observations per lane per tile
 constexpr int TILE_B = 64 * OPL_B;
 
-struct ViewLink {  // CSR of residual blocks per private view (Schur elimination)
-    std::vector<int64_t> off;
-    std::vector<int32_t> blk;
-};
-
 struct Engine {
     // ---- problem -----------------------------------------------------------------------------
     int chain = 0, model = 0;
@@ -195,21 +190,17 @@ struct Engine {
     DevBuf<double> blk_mom;   // [n_blocks][MomLayout::N] Mode B moment rows of the two-pose chains (kernels_reproj.hip)
     int modeb_moments = 1;    // 0 = accumulate the 12 pose columns directly (CBA_MODEB_MOMENTS=0, for A/B comparison)
 
-    // ---- LM / Schur state (lm_host.cpp, kernels_schur.hip) ------------------------------------
-    ViewLink links;
-    DevBuf<int64_t> d_link_off;
-    DevBuf<int32_t> d_link_blk;
+    // ---- LM / Schur state (backend_hip.hip, resident_lm.hip; the rest lives in HipLMState, lm_state.hpp) ----------
     DevBuf<double> blk_w;       // [n_blocks] Huber weights rho'(s_b)
     DevBuf<double> cam_acc;     // [n_cams][NACC] weighted per-camera sums
-    DevBuf<double> view_L;      // [n_views][21] Cholesky factor of damped H_pp
+    DevBuf<double> view_L;      // [n_views][36] Cholesky factor of damped H_pp (lower, row-major)
     DevBuf<double> view_y;      // [n_views][6]
     DevBuf<double> view_D;      // [n_views][6]  damping added to diag(H_pp)
     DevBuf<double> view_gp;     // [n_views][6]  g_p
     DevBuf<double> view_scale2; // [n_views][6]  jacobi scale^2
     DevBuf<double> blk_Z;       // [n_blocks][6][PSH]
     DevBuf<int32_t> view_fixed; // [n_views]
-    DevBuf<double> red_part, red_out, delta_sh, stats_part, stats_out;
-    int n_red_chunks = 0;
+    DevBuf<double> delta_sh;    // [nsh] shared step of the current trial
 
     // ---- collectives -------------------------------------------------------------------------
     cba_allreduce_fn allreduce = nullptr;

@@ -12,7 +12,7 @@ struct HipLMState {
     int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
     int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
     DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
-    DevBuf<int64_t> cchunk_off, cam_seg, link_off, one_seg;
+    DevBuf<int64_t> cchunk_off, cam_seg, link_off;
     DevBuf<int32_t> link_blk;
     DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
     DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination

@@ -43,7 +43,7 @@ struct ResidentArgs {
     double *bc, *sd;
     double *intr[2], *cam[2], *view[2], *target[2];
     double *partial, *blk_acc, *blk_s, *blk_w, *cam_acc;
-    double *view_L, *view_y, *view_D, *view_gp, *view_scale2, *blk_Z, *view_delta, *view_stats;
+    double *view_L, *view_y, *view_D, *view_gp, *view_scale2, *blk_Z, *view_delta;
     double *Hcc, *Ssch;
     const int8_t *active, *cam_var;
     int intr_var, target_var, constrained;
@@ -722,7 +722,7 @@ static ResidentArgs resident_args(Engine& e, HipLMState& st) {
     for (int k = 0; k < 2; ++k) { a.intr[k] = e.intr[k].p; a.cam[k] = e.cam[k].p; a.view[k] = e.view[k].p; a.target[k] = e.target[k].p; }
     a.partial = e.partial.p; a.blk_acc = e.blk_acc.p; a.blk_s = e.blk_s.p; a.blk_w = e.blk_w.p; a.cam_acc = e.cam_acc.p;
     a.view_L = e.view_L.p; a.view_y = e.view_y.p; a.view_D = e.view_D.p; a.view_gp = e.view_gp.p; a.view_scale2 = e.view_scale2.p;
-    a.blk_Z = e.blk_Z.p; a.view_delta = st.view_delta.p; a.view_stats = st.view_stats.p;
+    a.blk_Z = e.blk_Z.p; a.view_delta = st.view_delta.p;
     a.Hcc = st.res_Hcc.p; a.Ssch = st.res_Ssch.p;
     a.active = st.res_active.p; a.cam_var = st.res_cam_var.p;
     a.out = st.res_out.p;
