@@ -90,28 +90,31 @@ __global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_row_sum(int64_t n_rows,
     if (threadIdx.x < RS_COLS && e < width) out[e] = tot;
 }
 
-// single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4), out[w] = max_i aux[i] (if aux)
+// single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4); if aux: out[w] = max_i aux[i] and out[w + 1] = #{i : aux[i] < 0}
+// (k_schur_view marks a view whose damped H_pp is not positive definite with -1).  `out` may be page-locked host memory.
 __global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
                                                     double* __restrict__ out) {
-    __shared__ double sh[5][256];
-    double acc[4] = {0, 0, 0, 0}, mx = 0.0;
+    __shared__ double sh[6][256];
+    double acc[4] = {0, 0, 0, 0}, mx = 0.0, bad = 0.0;
     for (int i = static_cast<int>(threadIdx.x); i < n; i += 256) {
         for (int c = 0; c < w; ++c) acc[c] += in[static_cast<int64_t>(i) * w + c];
-        if (aux) mx = fmax(mx, aux[i]);
+        if (aux) { mx = fmax(mx, aux[i]); bad += aux[i] < 0.0 ? 1.0 : 0.0; }
     }
     for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] = acc[c];
     sh[4][threadIdx.x] = mx;
+    sh[5][threadIdx.x] = bad;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (static_cast<int>(threadIdx.x) < o) {
             for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
             sh[4][threadIdx.x] = fmax(sh[4][threadIdx.x], sh[4][threadIdx.x + o]);
+            sh[5][threadIdx.x] += sh[5][threadIdx.x + o];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         for (int c = 0; c < w; ++c) out[c] = sh[c][0];
-        out[w] = sh[4][0];
+        if (aux) { out[w] = sh[4][0]; out[w + 1] = sh[5][0]; }
     }
 }
 
@@ -120,7 +123,7 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
                              const int32_t* __restrict__ fixed, const double* __restrict__ lmp /*[radius, init_scale]*/, int constrained,
                              const double* __restrict__ view, double* __restrict__ scale2, double* __restrict__ L,
                              double* __restrict__ y, double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
-                             double* __restrict__ gmax, int* __restrict__ nfail) {
+                             double* __restrict__ gmax /* -1 marks a failed elimination */) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
@@ -131,8 +134,7 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
                                     constrained != 0, view + 7 * static_cast<int64_t>(v), scale2 + 6 * static_cast<int64_t>(v),
                                     L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
                                     gp + 6 * static_cast<int64_t>(v), blk_Z, &gm);
-    gmax[v] = ok ? gm : 0.0;
-    if (!ok) atomicAdd(nfail, 1);
+    gmax[v] = ok ? gm : -1.0;
 }
 
 // grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
@@ -255,23 +257,41 @@ __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ 
     for (int k = 0; k < 4; ++k) stats[4 * static_cast<int64_t>(v) + k] = o4[k];
 }
 
+// an accepted step: trial copies -> current copies (the shared pack and the private poses), one launch
+__global__ void k_accept(int64_t n_shared, const double* __restrict__ shared_trial, double* __restrict__ shared_cur, int64_t n_view,
+                         const double* __restrict__ view_trial, double* __restrict__ view_cur) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n_shared) shared_cur[i] = shared_trial[i];
+    if (i < n_view) view_cur[i] = view_trial[i];
+}
+
 static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(std::max<int64_t>(1, (n + per - 1) / per)); }
 
 // ---- Backend on an Engine (state: lm_state.hpp) -------------------------------------------------------
 struct HipBackend final : Backend {
     Engine& e;
     HipLMState& st;
-    explicit HipBackend(Engine& eng, HipLMState& s) : e(eng), st(s) {}
+    explicit HipBackend(Engine& eng, HipLMState& s) : e(eng), st(s) { st.current_is_on_device = false; }
 
     void set_view_fixed(const std::vector<int32_t>& f) override {
         if (!f.empty()) e.view_fixed.upload(f.data(), f.size(), e.stream);
         CBA_HIP(hipStreamSynchronize(e.stream));
     }
+    // Copy 0 goes up at once as ONE copy of the packed blocks (page-locked staging: queued, not blocking).  Copy 1 is only
+    // staged here: trial() uploads it together with the shared step.  Right after accept() the device already holds the
+    // accepted point in copy 0 (k_accept), so the driver's upload of the same values is skipped.
     void upload_shared(int which, const double* intr, const double* cam, const double* target) override {
-        e.intr[which].upload(intr, e.h_intr.size(), e.stream);
-        if (e.chain != CBA_CHAIN_INTRINSIC) e.cam[which].upload(cam, e.h_cam.size(), e.stream);
-        if (e.chain == CBA_CHAIN_BUNDLE) e.target[which].upload(target, 7, e.stream);
-        // pageable host memory: the copy has been staged when the call returns
+        if (which == 0 && st.current_is_on_device) { st.current_is_on_device = false; return; }
+        double* pk = st.pin_pack[which].p;
+        std::memcpy(pk, intr, sizeof(double) * e.h_intr.size());
+        if (e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(pk + e.pk_cam, cam, sizeof(double) * e.h_cam.size());
+        if (e.chain == CBA_CHAIN_BUNDLE) std::memcpy(pk + e.pk_target, target, sizeof(double) * 7);
+        if (which == 0) {
+            // the staging area may still be the source of the previous upload: wait for the stream first (rare path:
+            // start of a solve, covariance)
+            e.shared_pack[0].upload(pk, e.pk_delta, e.stream);
+            CBA_HIP(hipStreamSynchronize(e.stream));
+        }
     }
     // ---- stage plumbing: host preparation (every call) / device enqueue (captured once) / result collection ----------
     template <class F>
@@ -331,13 +351,12 @@ struct HipBackend final : Backend {
                            e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
         hipLaunchKernelGGL(k_cam_partial, dim3(std::max(1, st.n_cchunks)), dim3(256), 0, e.stream, s.NACC, st.cchunk_off.p,
                            st.cam_blk.p, e.blk_w.p, e.blk_acc.p, st.cam_partial.p);
-        hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
-                           s.NACC, st.cam_seg.p, st.cam_partial.p, e.cam_acc.p);
-        launch_cost(e, huber);
-        CBA_HIP(hipGetLastError());
+        // the stage's results are written straight into page-locked host memory (device-visible): no copy command on the stream
         const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
-        e.cam_acc.download(st.pin_ne.p, nca, e.stream);
-        e.scalar_out.download(st.pin_ne.p + nca, 2, e.stream);
+        hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
+                           s.NACC, st.cam_seg.p, st.cam_partial.p, st.pin_ne.p);
+        launch_cost(e, huber, st.pin_ne.p + nca);
+        CBA_HIP(hipGetLastError());
     }
     void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
         std::memcpy(cam_acc.data(), st.pin_ne.p, sizeof(double) * cam_acc.size());
@@ -360,12 +379,10 @@ struct HipBackend final : Backend {
     void enqueue_schur(bool constrained) {
         const Structure& s = st.s;
         const int n = s.nsh;
-        st.lmp.upload(st.pin_lmp.p, 2, e.stream);
-        CBA_HIP(hipMemsetAsync(st.nfail.p, 0, sizeof(int32_t), e.stream));
         hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.lmp.p, constrained ? 1 : 0,
+                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
                            e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
-                           st.view_gmax.p, st.nfail.p);
+                           st.view_gmax.p);
         if (n >= 64 && st.syrk_mfma)
             hipLaunchKernelGGL(k_schur_syrk_mfma, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
                                st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
@@ -373,24 +390,22 @@ struct HipBackend final : Backend {
             hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
                                st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
+        double* pack = st.pin.p;  // [syrk tiles | g_schur | gmax, #failed views] in page-locked host memory
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
-                           st.syrk_partial.p, st.schur_pack.p);
+                           st.syrk_partial.p, pack);
         hipLaunchKernelGGL(k_schur_gvec, dim3(st.n_vchunks), dim3(128), 0, e.stream, st.dims, s.n_views, n, st.view_cam_blk.p,
                            e.blk_Z.p, e.view_y.p, st.gvec_partial.p);
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
-                           static_cast<int64_t>(n), st.gvec_partial.p, st.schur_pack.p + sw);
-        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p,
-                           st.schur_pack.p + sw + n);
+                           static_cast<int64_t>(n), st.gvec_partial.p, pack + sw);
+        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p, pack + sw + n);
         CBA_HIP(hipGetLastError());
-        st.schur_pack.download(st.pin.p, static_cast<size_t>(sw) + n + 1, e.stream);
-        st.nfail.download(st.pin_i.p, 1, e.stream);
     }
     void collect_schur(std::vector<double>& S, std::vector<double>& g, double* gmax_priv, int* nfail) {
         const Structure& s = st.s;
         const int n = s.nsh;
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         const double* tiles = st.pin.p;
-        const int32_t nf = st.pin_i.p[0];
+        const int32_t nf = static_cast<int32_t>(tiles[static_cast<size_t>(sw) + n + 1] + 0.5);
         for (int i = 0; i < n; ++i) g[i] = tiles[static_cast<size_t>(sw) + i];
         *gmax_priv = tiles[static_cast<size_t>(sw) + n];
         *nfail = nf;
@@ -442,22 +457,21 @@ struct HipBackend final : Backend {
         const Structure& s = st.s;
         *out = TrialStats();
         if (s.n_blocks == 0) return;
-        std::memcpy(st.pin_delta.p, delta_sh, sizeof(double) * s.nsh);
+        std::memcpy(st.pin_pack[1].p + e.pk_delta, delta_sh, sizeof(double) * s.nsh);
         run_stage(st.g_trial, huber, false, [&] {
-            e.delta_sh.upload(st.pin_delta.p, s.nsh, e.stream);
+            e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta + static_cast<size_t>(s.nsh), e.stream);  // trial blocks + step
             if (s.n_views > 0) {
                 hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                    st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
                                    e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
                 hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
-                                   static_cast<const double*>(nullptr), st.small_out.p + 8);
+                                   static_cast<const double*>(nullptr), st.pin_tr.p + 8);
             }
             // cost at the trial point (Mode R); blk_s / blk_w of the ACCEPTED point stay in blk_acc / blk_w
             launch_block_consts(e, 1);
-            launch_resid_trial(e, huber);
+            launch_resid(e);  // Mode R writes blk_s; blk_acc / blk_w keep the accepted point's values
+            launch_cost(e, huber, st.pin_tr.p + 24);
             CBA_HIP(hipGetLastError());
-            st.small_out.download(st.pin_tr.p, 24, e.stream);
-            e.scalar_out.download(st.pin_tr.p + 24, 2, e.stream);
         });
         CBA_HIP(hipStreamSynchronize(e.stream));
         e.active = 1;
@@ -469,14 +483,12 @@ struct HipBackend final : Backend {
         out->dHd = s.n_views > 0 ? h[11] : 0.0;
         out->cost = c2[0];
     }
-    void launch_resid_trial(Engine& eng, double huber) {
-        // Mode R writes blk_s; keep the accepted point's s_b (needed by nobody after k_weights) simple:
-        launch_resid(eng);
-        launch_cost(eng, huber);
-    }
     void accept() override {
-        if (!e.h_view.empty())
-            CBA_HIP(hipMemcpyAsync(e.view[0].p, e.view[1].p, sizeof(double) * e.h_view.size(), hipMemcpyDeviceToDevice, e.stream));
+        const int64_t n_shared = static_cast<int64_t>(e.pk_delta), n_view = static_cast<int64_t>(e.h_view.size());
+        hipLaunchKernelGGL(k_accept, dim3(nblk(std::max(n_shared, n_view), 256)), dim3(256), 0, e.stream, n_shared, e.shared_pack[1].p,
+                           e.shared_pack[0].p, n_view, e.view[1].p, e.view[0].p);
+        CBA_HIP(hipGetLastError());
+        st.current_is_on_device = true;
     }
     void download_private(double* view_pose) override {
         if (e.h_view.empty()) return;
@@ -522,7 +534,6 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     up64(st->link_off, s.link_off);
     up32(st->link_blk, s.link_blk);
     up32(st->view_cam_blk, s.view_cam_blk);
-    st->nfail.alloc(1);
     st->cam_partial.alloc(static_cast<size_t>(std::max(1, st->n_cchunks)) * s.NACC);
     const size_t nv = std::max(1, s.n_views);
     st->view_gmax.alloc(nv);
@@ -530,18 +541,14 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->view_delta.zero(e.stream);
     st->view_stats.alloc(nv * 4);
     st->syrk_partial.alloc(static_cast<size_t>(st->n_vchunks) * st->n_pairs * 4096);
-    st->schur_pack.alloc(static_cast<size_t>(st->n_pairs) * 4096 + s.nsh + 8);
     st->gvec_partial.alloc(static_cast<size_t>(st->n_vchunks) * s.nsh);
-    st->small_out.alloc(32);
-    st->small_out.zero(e.stream);
     // pinned staging of everything a captured stage copies (sizes are fixed per problem: nothing is allocated in a capture)
     st->pin.reserve(static_cast<size_t>(st->n_pairs) * 4096 + s.nsh + 8);
     st->pin_ne.reserve(static_cast<size_t>(s.n_cams) * s.NACC + 2);
     st->pin_tr.reserve(32);
-    st->pin_i.reserve(1);
     st->pin_lmp.reserve(2);
-    st->pin_delta.reserve(std::max(1, s.nsh));
-    st->lmp.alloc(2);
+    st->pin_pack[0].reserve(e.pk_size);
+    st->pin_pack[1].reserve(e.pk_size);
     {   // ROCm loads a translation unit's code object on the first use of one of its kernels (milliseconds for the
         // template-heavy ones): touch both units here so that the first solve does not pay for it
         hipFuncAttributes fa;
@@ -565,7 +572,6 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     e.view_fixed.zero(e.stream);
     e.blk_Z.alloc(static_cast<size_t>(std::max(1, s.n_blocks)) * 6 * s.PSH);
     e.blk_Z.zero(e.stream);
-    e.delta_sh.alloc(s.nsh);
     // resident LM (resident_lm.hip)
     up64(st->cam_off, s.cam_off);
     st->res_active.alloc(std::max(1, s.nsh));

@@ -317,12 +317,22 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     if (d.chain != CBA_CHAIN_INTRINSIC) e.h_cam.assign(d.cam_pose, d.cam_pose + 7 * static_cast<size_t>(d.n_cams));
     if (d.chain != CBA_CHAIN_BUNDLE && d.n_views > 0) e.h_view.assign(d.view_pose, d.view_pose + 7 * static_cast<size_t>(d.n_views));
     if (d.chain == CBA_CHAIN_BUNDLE) e.h_target.assign(d.target_pose, d.target_pose + 7);
-    for (int k = 0; k < 2; ++k) {
-        e.intr[k].alloc(e.h_intr.size());
-        e.cam[k].alloc(e.h_cam.size());
-        e.view[k].alloc(std::max<size_t>(e.h_view.size(), 7));
-        e.target[k].alloc(7);
+    {
+        auto even = [](size_t n) { return (n + 1) & ~size_t(1); };
+        e.pk_cam = even(e.h_intr.size());
+        e.pk_target = e.pk_cam + even(e.h_cam.size());
+        e.pk_delta = e.pk_target + 8;
+        e.pk_size = e.pk_delta + even(static_cast<size_t>(st.nsh));
     }
+    for (int k = 0; k < 2; ++k) {
+        e.shared_pack[k].alloc(e.pk_size);
+        e.shared_pack[k].zero(e.stream);
+        e.intr[k].view(e.shared_pack[k].p, e.h_intr.size());
+        e.cam[k].view(e.shared_pack[k].p + e.pk_cam, e.h_cam.size());
+        e.target[k].view(e.shared_pack[k].p + e.pk_target, 7);
+        e.view[k].alloc(std::max<size_t>(e.h_view.size(), 7));
+    }
+    e.delta_sh.view(e.shared_pack[1].p + e.pk_delta, static_cast<size_t>(st.nsh));
     upload_params(e);
     e.bc.alloc(static_cast<size_t>(d.n_blocks) * 36);
     e.sd.alloc(static_cast<size_t>(d.n_cams) * 36);

@@ -62,6 +62,7 @@ struct DevBuf {
     size_t n = 0;
     size_t granted = 0;  // bytes of the underlying block
     int device = 0;
+    bool owned = true;   // false: a view into another buffer (view())
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -70,14 +71,19 @@ struct DevBuf {
     // synchronised their stream before buffers go out of scope; unwinding from an exception and replacing a live buffer
     // have not, so those wait for the device.
     void release() {
-        if (p) {
+        if (p && owned) {
             if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
             cache_release(false, device, p, granted);
         }
-        p = nullptr; n = 0; granted = 0;
+        p = nullptr; n = 0; granted = 0; owned = true;
+    }
+    // non-owning window of `count` elements at `ptr` (inside a buffer that outlives this one)
+    void view(T* ptr, size_t count) {
+        release();
+        p = ptr; n = count; owned = false;
     }
     void alloc(size_t count) {
-        if (p) (void)hipDeviceSynchronize();
+        if (p && owned) (void)hipDeviceSynchronize();
         release();
         if (count == 0) count = 1;
         CBA_HIP(hipGetDevice(&device));
@@ -176,6 +182,11 @@ struct Engine {
     int scalar = 0;  // 0 = fp64 per-observation arithmetic, 1 = fp32 (accumulators stay fp64)
     DevBuf<float> Xf, Yf, uf, vf, Jf, bcf, sdf, intrf;
     DevBuf<double> bc, sd, aux;  // aux: bundle b_T_g [n_blocks][12]
+    // The SHARED parameter blocks of copy k live side by side in shared_pack[k] = [intr | cam poses | target pose | shared step]
+    // (intr[k], cam[k], target[k], delta_sh are windows into it): a trial point goes up as ONE copy and is accepted by one
+    // small kernel (backend_hip.hip k_accept).  Declared before its windows.
+    DevBuf<double> shared_pack[2];
+    size_t pk_cam = 0, pk_target = 0, pk_delta = 0, pk_size = 0;  // offsets (doubles) of the windows
     DevBuf<double> intr[2], cam[2], view[2], target[2];
     int eval_blocked = 1;  // Mode A output layout: 1 tile-blocked out[tile][2+2P][128] (default), 0 whole-array columns
     int eval_done = 0, eval_blocked_last = 0;
@@ -221,7 +232,7 @@ void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
 void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2
 void warm_reproj_kernels();                              // forces the code object of kernels_reproj.hip to load
 void launch_normal_eq(Engine& e);                       // Mode B: blk_acc[b] = [H | g | s]
-void launch_cost(Engine& e, double huber_delta);        // scalar_out[0] = 1/2 sum rho(blk_s)
+void launch_cost(Engine& e, double huber_delta, double* out = nullptr);  // out (default scalar_out) = {1/2 sum rho(blk_s), sum blk_s}
 
 // backend_hip.hip
 void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records = false);

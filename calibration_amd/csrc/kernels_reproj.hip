@@ -481,14 +481,15 @@ void launch_resid(Engine& e) {
     CBA_HIP(hipGetLastError());
 }
 
-void launch_cost(Engine& e, double huber_delta) {
+void launch_cost(Engine& e, double huber_delta, double* out) {
+    if (!out) out = e.scalar_out.p;
     if (e.n_blocks > 4096) {
         const int n_part = (e.n_blocks + 2047) / 2048;
         if (e.cost_part.n < static_cast<size_t>(2 * n_part)) e.cost_part.alloc(static_cast<size_t>(2 * n_part));
         hipLaunchKernelGGL(k_cost_partial, dim3(n_part), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.cost_part.p);
-        hipLaunchKernelGGL(k_cost_final, dim3(1), dim3(64), 0, e.stream, n_part, e.cost_part.p, e.scalar_out.p);
+        hipLaunchKernelGGL(k_cost_final, dim3(1), dim3(64), 0, e.stream, n_part, e.cost_part.p, out);
     } else
-        hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, e.scalar_out.p);
+        hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, e.stream, e.n_blocks, e.blk_s.p, huber_delta, out);
     CBA_HIP(hipGetLastError());
 }
 

@@ -11,13 +11,15 @@ struct HipLMState {
     SchurDims dims;
     int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
     int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
-    DevBuf<int32_t> view_cam_blk, cam_blk, nfail;
+    DevBuf<int32_t> view_cam_blk, cam_blk;
     DevBuf<int64_t> cchunk_off, cam_seg, link_off;
     DevBuf<int32_t> link_blk;
-    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial, small_out;
-    DevBuf<double> schur_pack;  // [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax (1)] -> one D2H per elimination
-    PinnedBuf<double> pin, pin_ne, pin_tr;  // host staging of every per-step D2H result (one stream sync per stage)
-    PinnedBuf<int32_t> pin_i;
+    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial;
+    // Results of a stage land DIRECTLY in page-locked host memory (device-visible): the last kernels of the stage write there,
+    // so there is no copy command between the kernels and the one stream synchronisation.
+    //   pin    [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax, #failed views]      pin_ne [camera sums | cost, sum s]
+    //   pin_tr [8..12): step2, xnorm2, g^T d, d^T H d;  [24..26): trial cost, sum s
+    PinnedBuf<double> pin, pin_ne, pin_tr;
     // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
     // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
     // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches
@@ -35,8 +37,9 @@ struct HipLMState {
     int graph_after = 200;// capture + instantiate cost ~1 ms per stage on ROCm 7.2: only pays for itself on solves longer
                           // than a solve, so a stage runs as plain launches until it has been used this many times with
                           // the same key — i.e. on handles that are solved again and again (CBA_LM_GRAPH=<n>, 1 = at once, 0 = never)
-    DevBuf<double> lmp;          // device [radius, init_scale]
-    PinnedBuf<double> pin_lmp, pin_delta;
+    PinnedBuf<double> pin_lmp;      // [radius, init_scale]: k_schur_view reads it in place (wave-uniform, two numbers)
+    PinnedBuf<double> pin_pack[2];  // staging of Engine::shared_pack[k]: [intr | cam | target | shared step]
+    bool current_is_on_device = false;  // set by accept(): copy 0 on the device already equals the driver's next upload
     // resident LM (resident_lm.hip): per-camera block lists, the masks of the current options, reduced-system scratch
     int resident_mode = 1;             // 0 never, 1 when the problem is small (default), 2 whenever the kernel can run it
     int64_t resident_max_obs = 8192;   // "small": at most this many observations; set per chain in init_lm_state from the
