@@ -35,6 +35,35 @@ __global__ void k_weights(int n_blocks, int NACC, int s_idx, const double* __res
     blk_s[b] = s;
 }
 
+// k_weights and k_cost (kernels_reproj.hip) in one launch for up to 4096 blocks: the same per-thread strides and the same LDS
+// tree as k_cost, so the cost is bit-identical to the two-kernel form.  out = {1/2 sum rho(s_b), sum s_b} (may be pinned host memory)
+__global__ __launch_bounds__(256) void k_weights_cost(int n_blocks, int NACC, int s_idx, const double* __restrict__ blk_acc,
+                                                      double huber_delta, double* __restrict__ blk_w, double* __restrict__ blk_s,
+                                                      double* __restrict__ out) {
+    __shared__ double sh[2][256];
+    double c = 0.0, ss = 0.0;
+    for (int b = static_cast<int>(threadIdx.x); b < n_blocks; b += 256) {
+        const double s = blk_acc[static_cast<int64_t>(b) * NACC + s_idx];
+        double rho, w;
+        huber(s, huber_delta, &rho, &w);
+        blk_w[b] = w;
+        blk_s[b] = s;
+        c += 0.5 * rho;
+        ss += s;
+    }
+    sh[0][threadIdx.x] = c;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; }
+}
+
 // partial[k][e] = sum over chunk k's blocks (in list order) of w_b * acc[b][e]
 __global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ cam_blk,
                               const double* __restrict__ blk_w, const double* __restrict__ blk_acc,
@@ -137,11 +166,25 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
     gmax[v] = ok ? gm : -1.0;
 }
 
+// g_schur partial of one view chunk: out[g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k] (fixed order); run by the (chunk, pair 0)
+// workgroup of the syrk kernels so that the whole elimination result is one partial row per chunk and ONE k_row_sum
+__device__ __forceinline__ void schur_gvec_chunk(const SchurDims& d, int n_views, int nsh, int v0, const int32_t* __restrict__ view_cam_blk,
+                                                 const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ out) {
+    const int v1 = min(n_views, v0 + VCHUNK);
+    for (int g = threadIdx.x; g < nsh; g += blockDim.x) {
+        double s = 0.0;
+        for (int v = v0; v < v1; ++v)
+            for (int k = 0; k < 6; ++k) s += z_entry(d, view_cam_blk, blk_Z, v, g, k, nsh) * y[6 * static_cast<int64_t>(v) + k];
+        out[g] = s;
+    }
+}
+
 // grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
-// partial[chunk][pair][64*64]
+// partial[chunk] = [pair][64*64] then g_schur[nsh]  (row stride n_pairs * 4096 + nsh)
 __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, int nsh, int n_tiles,
                                                     const int32_t* __restrict__ view_cam_blk,
-                                                    const double* __restrict__ blk_Z, double* __restrict__ partial) {
+                                                    const double* __restrict__ blk_Z, const double* __restrict__ y,
+                                                    double* __restrict__ partial) {
     __shared__ double Zi[6][64], Zj[6][64];
     // decode the upper-triangular tile pair
     int pair = blockIdx.y, ti = 0;
@@ -176,11 +219,13 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
                 for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
         }
     }
-    double* out = partial + (static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * 4096;
+    double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
+    double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
+    if (blockIdx.y == 0) schur_gvec_chunk(d, n_views, nsh, v0, view_cam_blk, blk_Z, y, row + static_cast<int64_t>(gridDim.y) * 4096);
 }
 
 // The same contraction on the matrix cores, used when the shared block is a real contraction (nsh >= 64: the 8-camera rig of
@@ -194,7 +239,8 @@ constexpr int SYRK_ROWS = 6 * VCHUNK;  // 48, a multiple of 4
 
 __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_views, int nsh, int n_tiles,
                                                          const int32_t* __restrict__ view_cam_blk,
-                                                         const double* __restrict__ blk_Z, double* __restrict__ partial) {
+                                                         const double* __restrict__ blk_Z, const double* __restrict__ y,
+                                                         double* __restrict__ partial) {
     __shared__ double Zi[SYRK_ROWS][64], Zj[SYRK_ROWS][64];
     int pair = blockIdx.y, ti = 0;
     while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
@@ -221,24 +267,13 @@ __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_view
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zj[r][c * 16 + li], acc[c], 0, 0, 0);
     }
-    double* out = partial + (static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * 4096;
+    double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
+    double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) out[(wave * 16 + lk + 4 * reg) * 64 + c * 16 + li] = acc[c][reg];
-}
-
-// partial[chunk][g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k]
-__global__ void k_schur_gvec(SchurDims d, int n_views, int nsh, const int32_t* __restrict__ view_cam_blk,
-                             const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
-    const int v0 = blockIdx.x * VCHUNK;
-    const int v1 = min(n_views, v0 + VCHUNK);
-    for (int g = threadIdx.x; g < nsh; g += blockDim.x) {
-        double s = 0.0;
-        for (int v = v0; v < v1; ++v)
-            for (int k = 0; k < 6; ++k) s += z_entry(d, view_cam_blk, blk_Z, v, g, k, nsh) * y[6 * static_cast<int64_t>(v) + k];
-        partial[static_cast<int64_t>(blockIdx.x) * nsh + g] = s;
-    }
+    if (blockIdx.y == 0) schur_gvec_chunk(d, n_views, nsh, v0, view_cam_blk, blk_Z, y, row + static_cast<int64_t>(gridDim.y) * 4096);
 }
 
 __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
@@ -347,15 +382,20 @@ struct HipBackend final : Backend {
         const Structure& s = st.s;
         launch_block_consts(e, 0);
         launch_normal_eq(e);
-        hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
-                           e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
+        const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
+        const bool fused_cost = s.n_blocks <= 4096;
+        if (fused_cost)
+            hipLaunchKernelGGL(k_weights_cost, dim3(1), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL, e.blk_acc.p, huber,
+                               e.blk_w.p, e.blk_s.p, st.pin_ne.p + nca);
+        else
+            hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
+                               e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
         hipLaunchKernelGGL(k_cam_partial, dim3(std::max(1, st.n_cchunks)), dim3(256), 0, e.stream, s.NACC, st.cchunk_off.p,
                            st.cam_blk.p, e.blk_w.p, e.blk_acc.p, st.cam_partial.p);
         // the stage's results are written straight into page-locked host memory (device-visible): no copy command on the stream
-        const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
         hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
                            s.NACC, st.cam_seg.p, st.cam_partial.p, st.pin_ne.p);
-        launch_cost(e, huber, st.pin_ne.p + nca);
+        if (!fused_cost) launch_cost(e, huber, st.pin_ne.p + nca);
         CBA_HIP(hipGetLastError());
     }
     void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
@@ -383,20 +423,16 @@ struct HipBackend final : Backend {
                            st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
                            e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                            st.view_gmax.p);
+        const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         if (n >= 64 && st.syrk_mfma)
             hipLaunchKernelGGL(k_schur_syrk_mfma, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
-                               st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
+                               st.view_cam_blk.p, e.blk_Z.p, e.view_y.p, st.syrk_partial.p);
         else
             hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
-                               st.view_cam_blk.p, e.blk_Z.p, st.syrk_partial.p);
-        const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
+                               st.view_cam_blk.p, e.blk_Z.p, e.view_y.p, st.syrk_partial.p);
         double* pack = st.pin.p;  // [syrk tiles | g_schur | gmax, #failed views] in page-locked host memory
-        hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks), sw,
-                           st.syrk_partial.p, pack);
-        hipLaunchKernelGGL(k_schur_gvec, dim3(st.n_vchunks), dim3(128), 0, e.stream, st.dims, s.n_views, n, st.view_cam_blk.p,
-                           e.blk_Z.p, e.view_y.p, st.gvec_partial.p);
-        hipLaunchKernelGGL(k_row_sum, dim3(nblk(n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
-                           static_cast<int64_t>(n), st.gvec_partial.p, pack + sw);
+        hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw + n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
+                           sw + n, st.syrk_partial.p, pack);
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p, pack + sw + n);
         CBA_HIP(hipGetLastError());
     }
@@ -540,8 +576,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->view_delta.alloc(nv * 6);
     st->view_delta.zero(e.stream);
     st->view_stats.alloc(nv * 4);
-    st->syrk_partial.alloc(static_cast<size_t>(st->n_vchunks) * st->n_pairs * 4096);
-    st->gvec_partial.alloc(static_cast<size_t>(st->n_vchunks) * s.nsh);
+    st->syrk_partial.alloc(static_cast<size_t>(st->n_vchunks) * (static_cast<size_t>(st->n_pairs) * 4096 + s.nsh));  // + g_schur
     // pinned staging of everything a captured stage copies (sizes are fixed per problem: nothing is allocated in a capture)
     st->pin.reserve(static_cast<size_t>(st->n_pairs) * 4096 + s.nsh + 8);
     st->pin_ne.reserve(static_cast<size_t>(s.n_cams) * s.NACC + 2);

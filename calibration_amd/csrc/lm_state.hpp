@@ -14,7 +14,7 @@ struct HipLMState {
     DevBuf<int32_t> view_cam_blk, cam_blk;
     DevBuf<int64_t> cchunk_off, cam_seg, link_off;
     DevBuf<int32_t> link_blk;
-    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial, gvec_partial;
+    DevBuf<double> cam_partial, view_gmax, view_delta, view_stats, syrk_partial;  // syrk_partial[chunk] = [tiles | g_schur]
     // Results of a stage land DIRECTLY in page-locked host memory (device-visible): the last kernels of the stage write there,
     // so there is no copy command between the kernels and the one stream synchronisation.
     //   pin    [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax, #failed views]      pin_ne [camera sums | cost, sum s]
