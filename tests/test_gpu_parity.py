@@ -954,3 +954,32 @@ def test_create_from_observation_records_equals_flat_arrays(gpu_lib, kind):
         assert np.array_equal(np.asarray(a), np.asarray(b))
     with pytest.raises(ValueError):
         optim.ReprojHandle(copy.deepcopy(f), records=recs[:-1] + [np.zeros((0, 4))])  # record count differs from blk_offset
+
+
+@pytest.mark.parametrize("kind", ["intr", "ext", "bundle"])
+def test_hip_graph_replay_of_the_lm_stages_equals_plain_launches(gpu_lib, kind, monkeypatch, lm_mode):
+    """The host-driven iteration switches a stage to a captured HIP graph after 200 plain uses (CBA_LM_GRAPH=1: at once).
+    Capture + replay must reproduce the plain launches bit for bit, first solve (capture) and second solve (pure replay)."""
+    if lm_mode == "resident":
+        pytest.skip("graphs belong to the host-driven iteration")
+    o = options(epsilon=1e-10, optimize_intrinsics=1)
+
+    def run(graph):
+        monkeypatch.setenv("CBA_LM_GRAPH", graph)
+        sc = SCENES[kind](0, noise_px=0.3)
+        _perturb_intr(sc)
+        f = sc.flat
+        init = [None if x is None else x.copy() for x in (f.intr, f.cam_pose, f.view_pose, f.target_pose)]
+        out = []
+        with optim.ReprojHandle(f) as h:
+            for _ in range(2):
+                h.set_params(*init)
+                s = h.solve(o)
+                out.append((s.iterations, s.final_cost, f.intr.copy(), None if f.view_pose is None else f.view_pose.copy()))
+        return out
+
+    plain, graph = run("0"), run("1")
+    for a, b in zip(plain + plain[:1], graph + graph[1:]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[2], b[2])
+        assert (a[3] is None and b[3] is None) or np.array_equal(a[3], b[3])
