@@ -614,9 +614,6 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->res_Hcc.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_Ssch.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_out.alloc(32);
-    // crossover with the host-driven iteration (tools/exp_resident.py): one CU runs Mode B at ~16 ns per
-    // observation for P = 16 and ~50 ns for the two-pose chains (276-325 accumulators in six passes)
-    st->resident_max_obs = s.chain == CBA_CHAIN_INTRINSIC ? 8192 : (s.chain == CBA_CHAIN_EXTRINSIC ? 2048 : 1024);
     if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_RESIDENT_MAX_OBS")) st->resident_max_obs = std::atoll(env);
     CBA_HIP(hipStreamSynchronize(e.stream));

@@ -42,8 +42,8 @@ struct HipLMState {
     bool current_is_on_device = false;  // set by accept(): copy 0 on the device already equals the driver's next upload
     // resident LM (resident_lm.hip): per-camera block lists, the masks of the current options, reduced-system scratch
     int resident_mode = 1;             // 0 never, 1 when the problem is small (default), 2 whenever the kernel can run it
-    int64_t resident_max_obs = 8192;   // "small": at most this many observations; set per chain in init_lm_state from the
-                                       // measured crossover with the host-driven iteration (CBA_LM_RESIDENT_MAX_OBS overrides)
+    int64_t resident_max_obs = -1;     // >= 0: the automatic mode takes problems up to this many observations
+                                       // (CBA_LM_RESIDENT_MAX_OBS); -1: the measured crossover rule of resident_lm_eligible
     DevBuf<int64_t> cam_off;
     DevBuf<int8_t> res_active, res_cam_var;
     DevBuf<double> res_Hcc, res_Ssch, res_out;

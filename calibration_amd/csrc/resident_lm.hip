@@ -704,7 +704,14 @@ bool resident_lm_eligible(const Engine& e, const cba_options& o) {
     if (e.n_ranks != 1 || e.allreduce || e.rccl_comm) return false;  // the packed all-reduce lives in the host-driven iteration
     if (e.scalar != 0 || o.verbose) return false;
     if (s.n_blocks == 0 || s.nsh > RES_NSH_MAX || s.n_cams > RES_MAX_CAMS) return false;
-    if (st->resident_mode == 1 && s.n_obs > st->resident_max_obs) return false;
+    if (st->resident_mode == 1) {
+        if (st->resident_max_obs >= 0) return s.n_obs <= st->resident_max_obs;  // CBA_LM_RESIDENT_MAX_OBS
+        // Measured crossover with the host-driven iteration (tools/exp_resident.py, one MI355X): per LM step the resident
+        // kernel costs ~45 + 1.0 n_views + 0.0105 n_obs us on the intrinsic chain against ~108 + 0.003 n_obs host-driven;
+        // the two-pose chains need six register passes over 276-325 sums on ONE CU and only win on tiny problems.
+        if (s.chain == CBA_CHAIN_INTRINSIC) return 1.0 * s.n_views + 0.0075 * static_cast<double>(s.n_obs) <= 63.0;
+        return s.n_obs <= (s.chain == CBA_CHAIN_EXTRINSIC ? 1024 : 768);
+    }
     return true;
 }
 

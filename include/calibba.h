@@ -219,7 +219,8 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
  * single-workgroup kernel, for problems too small to fill the chip (the sizes the reference's own tests and pipelines run:
  * the host-driven iteration costs ~0.2 ms per LM step however little work it carries); falls back to 0 when the kernel cannot
  * take the problem (reduced system wider than 80, > 16 cameras).  1 (default): resident below the measured crossover with
- * the host-driven form (8192 observations for the intrinsic chain, 2048 extrinsic, 1024 bundle).
+ * the host-driven form (intrinsic chain: n_views + 0.0075 n_obs <= 63, e.g. 20 views x 280 points; extrinsic <= 1024 and
+ * bundle <= 768 observations).
  * Both forms follow the same rules and agree to rounding. */
 cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
 

@@ -896,7 +896,7 @@ def test_resident_kernel_is_the_default_for_small_problems_only(gpu_lib, monkeyp
     _perturb_intr(small)
     with optim.ReprojHandle(small.flat) as h:
         assert b"resident kernel" in bytes(h.solve(options()).report)
-    big = synth.scene_intrinsics(7, rows=40, cols=40, noise_px=0.2)  # 11 200 observations > 8192
+    big = synth.scene_intrinsics(7, rows=40, cols=40, noise_px=0.2)  # 11 200 observations: past the crossover
     _perturb_intr(big)
     with optim.ReprojHandle(big.flat) as h:
         assert b"resident" not in bytes(h.solve(options()).report)
