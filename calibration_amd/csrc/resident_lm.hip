@@ -69,13 +69,13 @@ struct ResidentShared {
     double radius, decrease_factor, cost, gmax, gmax_priv;
     int m, nfail, valid;
     unsigned long long prof[RES_PROF];
-    // the shared parameter blocks, current [0] and trial [1] (the serial Plus / gradient-norm code works here; the
+    // the shared parameter blocks, current [0] and trial [1] (Plus and the projected gradient norm work here; the
     // per-observation phases read the global copies, refreshed by publish_shared)
     double p_intr[2][RES_MAX_CAMS * 12], p_cam[2][RES_MAX_CAMS * 7], p_target[2][7];
 };
 
 // ---- workgroup reductions (fixed order) ------------------------------------------------------------------------------
-// sums of up to 4 values per thread; every thread returns with the totals in v[]
+// sums of up to 6 values per thread (red[][6]); every thread returns with the totals in v[]
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], ResidentShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
