@@ -13,6 +13,8 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <mutex>
+#include <set>
 
 #include "engine.hpp"
 #include "lm_core.hpp"
@@ -677,13 +679,21 @@ static LMDriver make_driver(Engine& e, HipBackend& be) {
 
 // One throw-away pass through the three LM stages at handle creation: the first launch of every kernel carries a
 // one-time cost on ROCm (code-object load, ~0.1-0.3 ms of per-kernel set-up) that added ~8 ms to the first solve of
-// a small problem; a handle that exists has paid it.  Results are discarded (every solve re-evaluates from the parameters).
+// a small problem.  Paid once per process, device and kernel family; results are discarded (every solve re-evaluates from
+// the parameters).
 void warm_lm(Engine& e) {
-    {   // a handle the resident kernel will serve warms that kernel instead (default options decide; other solves still work)
-        cba_options o{};
-        o.max_iterations = 1;
-        if (resident_lm_eligible(e, o)) { resident_lm_warm(e); return; }
+    cba_options o{};
+    o.max_iterations = 1;
+    const bool resident = resident_lm_eligible(e, o);  // default options decide which form this handle will use first
+    {   // the cost is per process and device (code objects, kernel set-up), not per handle: pay it once per kernel family
+        static std::mutex mu;
+        static std::set<uint32_t> warmed;
+        const uint32_t key = (static_cast<uint32_t>(e.device) << 8) | (resident ? 0x80u : 0u) | (static_cast<uint32_t>(e.chain) << 2) |
+                             static_cast<uint32_t>(e.model);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!warmed.insert(key).second) return;
     }
+    if (resident) { resident_lm_warm(e); return; }
     HipBackend be(e, *lm_state(e));
     const Structure& s = lm_state(e)->s;
     if (s.n_blocks == 0) return;
