@@ -222,29 +222,30 @@ __device__ __forceinline__ double shared_gmax(const ResidentArgs& a, ResidentSha
 }
 
 // LDS copy `from` of the shared blocks -> global copy `to` (and LDS copy `to`), by the whole workgroup
-__device__ __forceinline__ void publish_shared(const ResidentArgs& a, ResidentShared& sh, int from, int to) {
+__device__ __forceinline__ void publish_shared(const ResidentArgs& a, ResidentShared& sh, int from, int to, bool barrier = true) {
     const int PI = a.dims.PL - (a.dims.chain == CBA_CHAIN_INTRINSIC ? 6 : 12);
     for (int i = threadIdx.x; i < a.n_cams * PI; i += RES_THREADS) { const double x = sh.p_intr[from][i]; sh.p_intr[to][i] = x; a.intr[to][i] = x; }
     if (a.dims.chain != CBA_CHAIN_INTRINSIC)
         for (int i = threadIdx.x; i < a.n_cams * 7; i += RES_THREADS) { const double x = sh.p_cam[from][i]; sh.p_cam[to][i] = x; a.cam[to][i] = x; }
     if (a.dims.chain == CBA_CHAIN_BUNDLE)
         for (int i = threadIdx.x; i < 7; i += RES_THREADS) { const double x = sh.p_target[from][i]; sh.p_target[to][i] = x; a.target[to][i] = x; }
-    __syncthreads();
+    if (barrier) __syncthreads();
 }
 
 // ---- phases ------------------------------------------------------------------------------------------------------
 template <int CHAIN, int MODEL>
-__device__ __forceinline__ void phase_consts(const ResidentArgs& a, int which) {
+// (the shared blocks come from the LDS copies, so this needs no barrier after publish_shared; the private poses are global)
+__device__ __forceinline__ void phase_consts(const ResidentArgs& a, const ResidentShared& sh, int which) {
     for (int b = threadIdx.x; b < a.n_blocks; b += RES_THREADS) {
         const double *pA, *pB = nullptr, *ax = nullptr;
         if (CHAIN == CH_INTRINSIC) {
             pA = a.view[which] + 7 * static_cast<int64_t>(a.blk_view[b]);
         } else if (CHAIN == CH_EXTRINSIC) {
             pA = a.view[which] + 7 * static_cast<int64_t>(a.blk_view[b]);
-            pB = a.cam[which] + 7 * static_cast<int64_t>(a.blk_cam[b]);
+            pB = sh.p_cam[which] + 7 * a.blk_cam[b];
         } else {
-            pA = a.target[which];
-            pB = a.cam[which] + 7 * static_cast<int64_t>(a.blk_cam[b]);
+            pA = sh.p_target[which];
+            pB = sh.p_cam[which] + 7 * a.blk_cam[b];
             ax = a.aux + 12 * static_cast<int64_t>(b);
         }
         double o[BC_SIZE];
@@ -255,7 +256,7 @@ __device__ __forceinline__ void phase_consts(const ResidentArgs& a, int which) {
         for (int c = threadIdx.x; c < a.n_cams; c += RES_THREADS) {
             double o[SD_SIZE];
             for (int i = 0; i < SD_SIZE; ++i) o[i] = 0.0;
-            scheimpflug_consts(a.intr[which] + 12 * static_cast<int64_t>(c), o);
+            scheimpflug_consts(sh.p_intr[which] + 12 * c, o);
             for (int i = 0; i < SD_SIZE; ++i) a.sd[static_cast<int64_t>(c) * SD_SIZE + i] = o[i];
         }
     __syncthreads();
@@ -388,6 +389,12 @@ __device__ __forceinline__ void phase_assemble(const ResidentArgs& a, bool init_
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {  // compact list of the effective columns (read after the next phase's barriers)
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (sh.eff[i]) sh.idx[m++] = i;
+        sh.m = m;
+    }
 }
 
 // per-view elimination with sh.radius, then S_schur, g_schur
@@ -451,13 +458,7 @@ __device__ __forceinline__ void phase_schur(const ResidentArgs& a, bool init_sca
 // dot-product Cholesky and the substitution order of dense.hpp; the diagonal is applied as a reciprocal).
 __device__ __forceinline__ void phase_solve_reduced(const ResidentArgs& a, ResidentShared& sh) {
     const int n = a.nsh;
-    if (threadIdx.x == 0) {
-        int m = 0;
-        for (int i = 0; i < n; ++i)
-            if (sh.eff[i]) sh.idx[m++] = i;
-        sh.m = m;
-        sh.valid = sh.nfail > 0 ? 0 : 1;
-    }
+    if (threadIdx.x == 0) sh.valid = sh.nfail > 0 ? 0 : 1;
     for (int i = threadIdx.x; i < n; i += RES_THREADS) sh.delta[i] = 0.0;
     __syncthreads();
     const int m = sh.m;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
         }
     };
     auto new_system = [&](bool init_scale) {
-        phase_consts<CHAIN, MODEL>(a, 0);
+        phase_consts<CHAIN, MODEL>(a, sh, 0);
         tick(0);
         phase_mode_b<CHAIN, MODEL>(a);
         tick(1);
@@ -637,8 +638,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
                 const double model_change = -(st[2] + st[4]) - 0.5 * (st[3] + st[5]);
                 if (!(model_change > 0.0) || !(fabs(model_change) <= 1.7976931348623157e308)) valid = false;
                 if (valid) {
-                    publish_shared(a, sh, 1, 1);
-                    phase_consts<CHAIN, MODEL>(a, 1);
+                    publish_shared(a, sh, 1, 1, /*barrier=*/false);  // (from == to in LDS: only the global copies change)
+                    phase_consts<CHAIN, MODEL>(a, sh, 1);
                     double cand = phase_resid_cost<MODEL>(a, 1, sh);
                     tick(8);
                     if (!(fabs(cand) <= 1.7976931348623157e308)) cand = 1.7976931348623157e308;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
         }
     }
     __syncthreads();
-    phase_consts<CHAIN, MODEL>(a, 0);  // leave bc / sd at the accepted point
+    phase_consts<CHAIN, MODEL>(a, sh, 0);  // leave bc / sd at the accepted point
     if (tid == 0) {
         a.out[0] = term;
         a.out[1] = iter;
