@@ -260,8 +260,10 @@ void dlt_homography_batch(int n_views, const int64_t* view_offset, const double*
                           double* H9, int32_t* ok, int device);
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, double* pose7, int device);
-void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device);
+// fn / user / n_ranks / rank: multi-GPU form — this rank's share of the pairs, sums all-reduced through the host callback
+void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device,
+                 cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0);
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
-                   double* cov, int device);
+                   double* cov, int device, cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0);
 
 }  // namespace cba

@@ -18,9 +18,9 @@ namespace cba {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_axxb(int n, const double* __restrict__ poses /*[n][24]: Rb tb Rc tc*/,
                                               const double* __restrict__ X /*RX(9) tX(3)*/, double min_angle,
-                                              double axis_eps, double huber_delta, double* __restrict__ partial) {
+                                              double axis_eps, double huber_delta, int i_first, double* __restrict__ partial) {
     __shared__ double sh[4][AXXB_NACC];
-    const int i = blockIdx.y;
+    const int i = i_first + blockIdx.y;  // this launch covers first poses [i_first, i_first + gridDim.y)
     const int j = blockIdx.x * 256 + threadIdx.x;
     double acc[AXXB_NACC];
 #pragma unroll
@@ -80,7 +80,16 @@ struct HipAxxb final : AxxbEval {
     DevBuf<double> poses, X, partial, partial2, out;
     int64_t n_rows = 0, n_chunks = 0;
     dim3 grid;
-    HipAxxb(int n_poses, const double* bTg, const double* cTt) : n(n_poses) {
+    int i_first = 0;              // first poses [i_first, i_first + grid.y) are this rank's (axxb_rank_range)
+    cba_allreduce_fn reduce = nullptr;  // in-place sum of the 29 accumulated values over ranks (host callback)
+    void* reduce_user = nullptr;
+    HipAxxb(int n_poses, const double* bTg, const double* cTt, cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1,
+            int rank = 0)
+        : n(n_poses), reduce(n_ranks > 1 ? fn : nullptr), reduce_user(user) {
+        if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+        if (n_ranks > 1 && !fn) throw std::invalid_argument("multi-rank AX = XB needs an all-reduce callback");
+        int i_last = std::max(1, n - 1);
+        if (n_ranks > 1) axxb_rank_range(n, n_ranks, rank, &i_first, &i_last);
         std::vector<double> h(static_cast<size_t>(n) * 24);
         for (int k = 0; k < n; ++k) {
             // R from the (unit) quaternion exactly as Eigen::Isometry3d stored it before populate_quat_tran
@@ -91,14 +100,29 @@ struct HipAxxb final : AxxbEval {
             quat_to_rotmat(qc, &h[24 * static_cast<size_t>(k) + 12]);
             for (int a = 0; a < 3; ++a) { h[24 * static_cast<size_t>(k) + 9 + a] = bTg[7 * k + 4 + a]; h[24 * static_cast<size_t>(k) + 21 + a] = cTt[7 * k + 4 + a]; }
         }
-        grid = dim3((n + 255) / 256, std::max(1, n - 1));
+        grid = dim3((n + 255) / 256, std::max(0, i_last - i_first));  // y = 0: this rank has no pairs
         poses.alloc(h.size()); poses.upload(h.data(), h.size(), stream);
         X.alloc(12); out.alloc(AXXB_NACC);
         n_rows = static_cast<int64_t>(grid.x) * grid.y;
         n_chunks = (n_rows + 63) / 64;
-        partial.alloc(static_cast<size_t>(n_rows) * AXXB_NACC);
-        partial2.alloc(static_cast<size_t>(n_chunks) * AXXB_NACC);
+        partial.alloc(static_cast<size_t>(std::max<int64_t>(n_rows, 1)) * AXXB_NACC);
+        partial2.alloc(static_cast<size_t>(std::max<int64_t>(n_chunks, 1)) * AXXB_NACC);
         CBA_HIP(hipStreamSynchronize(stream));
+    }
+    // pair sums of this rank's range at X (already uploaded), two-level fixed-order sum, then the sum over ranks
+    template <int MODE>
+    void pass(double min_angle, double huber_delta, double* acc) {
+        if (grid.y > 0) {
+            hipLaunchKernelGGL(k_axxb<MODE>, grid, dim3(256), 0, stream, n, poses.p, X.p, min_angle, 1e-3, huber_delta, i_first, partial.p);
+            hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, stream, n_rows, int64_t{64}, partial.p, partial2.p);
+            hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, stream, n_chunks, n_chunks, partial2.p, out.p);
+            CBA_HIP(hipGetLastError());
+            out.download(acc, AXXB_NACC, stream);
+            CBA_HIP(hipStreamSynchronize(stream));
+        } else {
+            for (int e = 0; e < AXXB_NACC; ++e) acc[e] = 0.0;
+        }
+        if (reduce && reduce(acc, AXXB_NACC, reduce_user) != 0) throw std::runtime_error("allreduce callback failed");
     }
     ~HipAxxb() override { (void)hipStreamSynchronize(stream); }
     void eval(const double* pose7, double huber_delta, double* acc) override {
@@ -107,36 +131,26 @@ struct HipAxxb final : AxxbEval {
         for (int a = 0; a < 3; ++a) hx[9 + a] = pose7[4 + a];
         X.upload(hx, 12, stream);
         constexpr double kMinAngleDeg = 0.5;  // handeye.cpp:64
-        hipLaunchKernelGGL(k_axxb<0>, grid, dim3(256), 0, stream, n, poses.p, X.p, kMinAngleDeg * 3.14159265358979323846 / 180.0, 1e-3,
-                           huber_delta, partial.p);
-        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, stream, n_rows, int64_t{64}, partial.p, partial2.p);
-        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, stream, n_chunks, n_chunks, partial2.p, out.p);
-        CBA_HIP(hipGetLastError());
-        out.download(acc, AXXB_NACC, stream);
-        CBA_HIP(hipStreamSynchronize(stream));
+        pass<0>(kMinAngleDeg * 3.14159265358979323846 / 180.0, huber_delta, acc);
     }
 };
 }  // namespace
 
 // estimate_handeye_dlt (handeyedlt.cpp:126-137): two passes over all pose pairs on the device (rotation sums, then
 // translation sums at the estimated R_X), two 3x3 ridge solves on the host.  pose7 out.
-void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device) {
+void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device, cba_allreduce_fn fn,
+                 void* user, int n_ranks, int rank) {
     if (n_poses < 2 || !bTg || !cTt)  // handeyedlt.cpp:56-58
         throw std::runtime_error("Inconsistent hand-eye input sizes");
     CBA_HIP(hipSetDevice(device));
-    HipAxxb ev(n_poses, bTg, cTt);
+    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank);
     const double min_angle = min_angle_deg * 3.14159265358979323846 / 180.0;
     auto pass = [&](int mode, const double* RX, double* acc) {
         double hx[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
         if (RX) for (int k = 0; k < 9; ++k) hx[k] = RX[k];
         ev.X.upload(hx, 12, ev.stream);
-        if (mode == 0) hipLaunchKernelGGL(k_axxb<1>, ev.grid, dim3(256), 0, ev.stream, ev.n, ev.poses.p, ev.X.p, min_angle, 1e-3, 0.0, ev.partial.p);
-        else hipLaunchKernelGGL(k_axxb<2>, ev.grid, dim3(256), 0, ev.stream, ev.n, ev.poses.p, ev.X.p, min_angle, 1e-3, 0.0, ev.partial.p);
-        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(ev.n_chunks)), dim3(256), 0, ev.stream, ev.n_rows, int64_t{64}, ev.partial.p, ev.partial2.p);
-        hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, ev.stream, ev.n_chunks, ev.n_chunks, ev.partial2.p, ev.out.p);
-        CBA_HIP(hipGetLastError());
-        ev.out.download(acc, AXXB_NACC, ev.stream);
-        CBA_HIP(hipStreamSynchronize(ev.stream));
+        if (mode == 0) ev.pass<1>(min_angle, 0.0, acc);
+        else ev.pass<2>(min_angle, 0.0, acc);
     };
     double acc[AXXB_NACC], w[3], RX[9], t[3];
     pass(0, nullptr, acc);
@@ -151,11 +165,11 @@ void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_a
 }
 
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
-                   double* cov, int device) {
+                   double* cov, int device, cba_allreduce_fn fn, void* user, int n_ranks, int rank) {
     if (n_poses < 2 || !bTg || !cTt)  // handeyedlt.cpp:56-58
         throw std::runtime_error("Inconsistent hand-eye input sizes");
     CBA_HIP(hipSetDevice(device));
-    HipAxxb ev(n_poses, bTg, cTt);
+    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank);
     handeye_lm(ev, pose7, *o, s, (cov && o->compute_covariance) ? cov : nullptr);
 }
 

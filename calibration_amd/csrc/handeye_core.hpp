@@ -3,6 +3,7 @@
 // unknowns, a per-pair Huber loss.  Same restated Ceres trust-region semantics as lm_core.hpp
 // (unconstrained case).  The O(#pairs) evaluation is the Backend's (HIP kernel k_axxb).
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,6 +17,20 @@
 #include "dense.hpp"
 
 namespace cba {
+
+// Multi-GPU AX = XB: rank r evaluates the pairs (i, j > i) whose FIRST pose i lies in [i0, i1); the ranges
+// tile [0, n - 1) and are balanced by pair count (first pose i has n - 1 - i partners).
+inline void axxb_rank_range(int n, int n_ranks, int rank, int* i0, int* i1) {
+    const long long total = static_cast<long long>(n) * (n - 1) / 2;
+    auto first_with = [&](long long want) {  // smallest k with #pairs(first pose < k) >= want
+        int k = 0;
+        long long c = 0;
+        while (k < n - 1 && c < want) { c += n - 1 - k; ++k; }
+        return k;
+    };
+    *i0 = first_with(total * rank / n_ranks);
+    *i1 = rank == n_ranks - 1 ? std::max(0, n - 1) : first_with(total * (rank + 1) / n_ranks);
+}
 
 struct AxxbEval {
     virtual ~AxxbEval() = default;

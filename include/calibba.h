@@ -288,6 +288,16 @@ cba_status cba_estimate_and_optimize_handeye(int32_t n_poses, const double* base
                                              double min_angle_deg /*reference default 1.0*/, double* g_T_c /*[7] out*/,
                                              const cba_options* opts, cba_summary* summary, double* cov);
 
+/* The same two steps on several GPUs (AX = XB row): every rank passes ALL n poses; rank r evaluates the pairs
+ * (i, j > i) whose first pose i lies in its range (ranges balanced by pair count) and the 29 accumulated values
+ * [H | g | cost | #pairs] of every evaluation are summed over ranks through `fn` (the callback of cba_reproj_set_allreduce), so
+ * every rank runs the same LM on the same sums.  estimate != 0: start from the all-pairs Tsai-Lenz seed (g_T_c out), else refine
+ * g_T_c in place.  `device`: this rank's GPU. */
+cba_status cba_estimate_and_optimize_handeye_sharded(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                                     double min_angle_deg, int32_t estimate, double* g_T_c,
+                                                     const cba_options* opts, cba_summary* summary, double* cov,
+                                                     cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank, int32_t device);
+
 /* optimize_planar_pose (include/calib/estimation/optim/planarpose.h:24-26, src/estimation/optim/planarpose.cpp:84-127):
  * pose refinement of ONE planar view for fixed K = [fx, fy, cx, cy, skew] by variable projection over the
  * Brown-Conrady coefficients (num_radial radial + 2 tangential, PlanarPoseOptions::num_radial default 2).

@@ -52,6 +52,9 @@ void hm_axxb_eval(const double* q, const double* t, const double* RA, const doub
     axxb_point(RX, t, RA, RB, tA, tB, r6, J66);
 }
 
+// the product's partition of the AX = XB pairs over ranks (handeye_core.hpp)
+void hm_axxb_rank_range(int n, int n_ranks, int rank, int* i0, int* i1) { axxb_rank_range(n, n_ranks, rank, i0, i1); }
+
 // Tsai-Lenz all-pairs seed through the product's per-pair sums (axxb_math.hpp), serial; returns 0, 1 (no pairs) or 2 (singular)
 int hm_handeye_dlt(int n, const double* bTg, const double* cTt, double min_angle_deg, double* pose7) {
     CpuAxxb ev(n, bTg, cTt);

@@ -91,6 +91,8 @@ def load_hostmath():
     h.hm_axxb_eval.restype = None
     h.hm_build_pairs.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p]
     h.hm_handeye_dlt.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
+    h.hm_axxb_rank_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    h.hm_axxb_rank_range.restype = None
     h.hm_handeye_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, PO, PS, c_double_p]
     return h
 

@@ -708,3 +708,23 @@ def test_header_is_plain_c_and_the_c_example_links(lib, tmp_path):
     if lib.cba_device_count() <= 0:
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device visible" in r.stderr
+
+
+@pytest.mark.parametrize("n,world", [(2, 2), (3, 2), (18, 2), (18, 4), (2000, 8), (5, 8)])
+def test_axxb_pair_partition_over_ranks_tiles_and_balances(hostmath, n, world):
+    """axxb_rank_range (handeye_core.hpp, SURVEY.md §8e AX = XB row): the first-pose ranges of the ranks tile [0, n - 1) in
+    order, and no rank holds more than its fair share of the n (n - 1) / 2 pairs plus one first pose's worth."""
+    import ctypes as C
+
+    edges, pairs = [], []
+    for r in range(world):
+        i0, i1 = C.c_int(), C.c_int()
+        hostmath.hm_axxb_rank_range(n, world, r, C.byref(i0), C.byref(i1))
+        edges.append((i0.value, i1.value))
+        pairs.append(sum(n - 1 - i for i in range(i0.value, i1.value)))
+    assert edges[0][0] == 0 and edges[-1][1] == max(0, n - 1)
+    for (a0, a1), (b0, b1) in zip(edges[:-1], edges[1:]):
+        assert a0 <= a1 == b0 <= b1
+    total = n * (n - 1) // 2
+    assert sum(pairs) == total
+    assert max(pairs) <= total / world + (n - 1)

@@ -174,3 +174,63 @@ def test_two_ranks_on_the_gpu_engine_match_one_rank(tmp_path, kind, okw, world):
         assert np.array_equal(res[0]["intr"], r["intr"]) and np.array_equal(res[0]["cam"], r["cam"])
     views = np.concatenate([r["view"].reshape(-1, 7) for r in res])
     assert helpers.rel_diff(ref.view_pose.reshape(-1, 7), views) <= 1e-9
+
+
+# ---- AX = XB over ranks: pairs partitioned by their first pose, 29 sums all-reduced -----------------------------
+def _axxb_worker(rank, world, port, n_poses, outdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calibration_amd import optim
+    from calibration_amd.geometry import pose_from_matrix
+    from tests import helpers
+
+    bTg, cTt, _X_gt, _X0 = helpers.handeye_scene(n_poses, seed=11, noise_rot_deg=0.05, noise_trans=0.0005)
+    calls = []
+
+    def allreduce(arr):
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t)
+        calls.append(arr.size)
+
+    res = optim.optimize_handeye_sharded(bTg, cTt, allreduce, world, rank, init_gripper_se3_ref=None, min_angle_deg=1.0,
+                                         options=optim.OptimOptions(epsilon=1e-12), device=0)
+    np.savez(os.path.join(outdir, f"axxb{rank}.npz"), pose=pose_from_matrix(res.g_se3_c), cov=res.core.covariance,
+             cost=res.core.final_cost, success=res.core.success, ncalls=len(calls), sizes=np.array(calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_poses,world", [(18, 2), (40, 3), (3, 4)])
+def test_axxb_sharded_over_ranks_matches_one_gpu(tmp_path, n_poses, world):
+    """estimate_and_optimize_handeye with the motion pairs split over 2 / 3 / 4 ranks (each its own process on GPU 0, sums over
+    gloo; with 3 poses and 4 ranks two ranks hold no pair at all) against the single-GPU entry point."""
+    import torch.multiprocessing as mp
+
+    from calibration_amd import optim
+    from calibration_amd.geometry import pose_from_matrix
+    from tests import helpers
+
+    ctx = mp.start_processes(_axxb_worker, args=(world, _free_port(), n_poses, str(tmp_path)), nprocs=world, join=False, start_method="spawn")
+    import time
+
+    deadline = time.time() + 180
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("sharded AX = XB did not finish in 180 s")
+    bTg, cTt, _X_gt, _X0 = helpers.handeye_scene(n_poses, seed=11, noise_rot_deg=0.05, noise_trans=0.0005)
+    ref = optim.estimate_and_optimize_handeye(bTg, cTt, 1.0, optim.OptimOptions(epsilon=1e-12))
+    ref_pose = pose_from_matrix(ref.g_se3_c)
+    res = [np.load(os.path.join(tmp_path, f"axxb{r}.npz")) for r in range(world)]
+    for r in res:
+        assert bool(r["success"]) == ref.core.success and int(r["ncalls"]) >= 3 and set(r["sizes"].tolist()) == {29}
+        assert np.abs(r["pose"] - ref_pose).max() <= 1e-10
+        assert abs(float(r["cost"]) - ref.core.final_cost) <= 1e-10 * max(1.0, ref.core.final_cost)
+        assert np.abs(r["cov"] - ref.core.covariance).max() <= 1e-8 * np.abs(ref.core.covariance).max()
+    for r in res[1:]:  # every rank ran the same LM on the same sums
+        assert np.array_equal(res[0]["pose"], r["pose"])
