@@ -131,6 +131,8 @@ PROTOTYPES = {
     "cba_last_error": (C.c_char_p, []),
     "cba_device_count": (C.c_int32, []),
     "cba_trim_cache": (None, []),
+    "cba_set_device": (C.c_int32, [C.c_int32]),
+    "cba_get_device": (C.c_int32, []),
     "cba_options_default": (None, [C.POINTER(CbaOptions)]),
     "cba_intrinsics_size": (C.c_int32, [C.c_int32]),
     "cba_local_columns": (C.c_int32, [C.c_int32, C.c_int32]),

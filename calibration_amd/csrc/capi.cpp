@@ -5,6 +5,7 @@
 // There is no CPU arithmetic path: without a HIP device every compute call returns
 // CBA_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -45,6 +46,10 @@ static cba_status guarded(F&& f) {
         return CBA_ERR_INTERNAL;
     }
 }
+
+// the device of the entry points that take no handle and no device argument (one process per GPU: cba_set_device(LOCAL_RANK))
+static std::atomic<int> g_default_device{0};
+static int default_device() { return g_default_device.load(); }
 
 static int device_count() {
     int n = 0;
@@ -360,6 +365,15 @@ const char* cba_version(void) { return CBA_VERSION_STRING; }
 const char* cba_last_error(void) { return g_err.c_str(); }
 int32_t cba_device_count(void) { return device_count(); }
 void cba_trim_cache(void) { try { cache_trim(); } catch (...) {} }
+cba_status cba_set_device(int32_t device) {
+    return guarded([&] {
+        const int n = device_count();
+        if (n <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        if (device < 0 || device >= n) throw std::invalid_argument("device index out of range");
+        g_default_device.store(device);
+    });
+}
+int32_t cba_get_device(void) { return default_device(); }
 
 void cba_options_default(cba_options* o) {
     std::memset(o, 0, sizeof(*o));
@@ -727,7 +741,7 @@ static void one_shot(const cba_reproj_problem& d, const cba_options* opts, cba_s
     if (!opts || !summary) throw std::invalid_argument("null argument");
     PhaseTimer pt;
     auto e = std::make_unique<Engine>();
-    build_engine(d, 0, *e);
+    build_engine(d, default_device(), *e);
     pt.lap("one-shot: handle");
     solve_lm(*e, *opts, summary);
     pt.lap("one-shot: solve");
@@ -807,7 +821,7 @@ cba_status cba_optimize_handeye(int32_t n_poses, const double* base_T_gripper, c
     return guarded([&] {
         if (!opts || !summary || !g_T_c) throw std::invalid_argument("null argument");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
-        handeye_solve(n_poses, base_T_gripper, cam_T_target, g_T_c, opts, summary, cov, 0);
+        handeye_solve(n_poses, base_T_gripper, cam_T_target, g_T_c, opts, summary, cov, default_device());
     });
 }
 
@@ -817,7 +831,7 @@ cba_status cba_estimate_handeye_dlt(int32_t n_poses, const double* base_T_grippe
         if (!g_T_c) throw std::invalid_argument("null argument");
         if (n_poses < 2 || !base_T_gripper || !cam_T_target) throw std::runtime_error("Inconsistent hand-eye input sizes");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
-        handeye_dlt(n_poses, base_T_gripper, cam_T_target, min_angle_deg, g_T_c, 0);
+        handeye_dlt(n_poses, base_T_gripper, cam_T_target, min_angle_deg, g_T_c, default_device());
     });
 }
 
@@ -850,7 +864,7 @@ cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_o
     return guarded([&] {
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
         planar_pose_batch(n_views, view_offset, X, Y, u, v, kmtx5, num_radial, pose7, opts, summaries, distortion, reprojection_error,
-                          cov36, 0);
+                          cov36, default_device());
     });
 }
 
@@ -871,7 +885,7 @@ cba_status cba_optimize_homography_batch(int32_t n_views, const int64_t* view_of
         for (int i = 0; i < n_views; ++i)  // homography.cpp:146-148, checked before any device work like the reference
             if (view_offset[i + 1] - view_offset[i] < 4) throw std::invalid_argument("At least 4 correspondences are required.");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
-        homography_batch(n_views, view_offset, X, Y, u, v, h9, opts, summaries, cov64, 0);
+        homography_batch(n_views, view_offset, X, Y, u, v, h9, opts, summaries, cov64, default_device());
     });
 }
 
@@ -903,7 +917,7 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
                 throw std::invalid_argument("bad view offsets");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
         semidlt_solve(n_views, view_offset, X, Y, u, v, kmtx5, c_T_t, num_radial, bounds_lo5, bounds_hi5, fixed_idx, fixed_val, n_fixed,
-                      opts, summary, distortion, view_errors, (cov && opts->compute_covariance) ? cov : nullptr, 0);
+                      opts, summary, distortion, view_errors, (cov && opts->compute_covariance) ? cov : nullptr, default_device());
     });
 }
 
@@ -915,7 +929,7 @@ cba_status cba_estimate_homography_batch(int32_t n_views, const int64_t* view_of
             if (view_offset[i + 1] < view_offset[i] || view_offset[i + 1] - view_offset[i] > 0x7fffffff)
                 throw std::invalid_argument("bad view offsets");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
-        dlt_homography_batch(n_views, view_offset, X, Y, u, v, h9, success, 0);
+        dlt_homography_batch(n_views, view_offset, X, Y, u, v, h9, success, default_device());
     });
 }
 
@@ -927,7 +941,7 @@ cba_status cba_estimate_planar_pose_batch(int32_t n_views, const int64_t* view_o
             if (view_offset[i + 1] < view_offset[i] || view_offset[i + 1] - view_offset[i] > 0x7fffffff)
                 throw std::invalid_argument("bad view offsets");
         if (device_count() <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
-        planar_seed_batch(n_views, view_offset, X, Y, u, v, kmtx5, pose7, 0);
+        planar_seed_batch(n_views, view_offset, X, Y, u, v, kmtx5, pose7, default_device());
     });
 }
 

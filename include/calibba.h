@@ -151,6 +151,11 @@ int32_t cba_device_count(void);   /* number of visible HIP devices (0 if none) *
  * their stream to a process-wide cache instead of the runtime: a pipeline that calls optimize_* stage after stage pays for the
  * allocations once (releasing them was 1.9 ms of a 5 ms call at the reference's test sizes).  This frees what the cache holds. */
 void cba_trim_cache(void);
+/* The device used by every entry point that takes neither a handle nor a device argument (the one-shot cba_optimize_* calls, the
+ * batched per-view solvers and seeds).  Default 0.  With one process per GPU call cba_set_device(LOCAL_RANK) once: the batched
+ * solvers have no exchange step, so several GPUs simply take slices of the views. */
+cba_status cba_set_device(int32_t device);
+int32_t cba_get_device(void);
 void cba_options_default(cba_options* o);
 int32_t cba_intrinsics_size(int32_t camera_model); /* 10 or 12 */
 int32_t cba_local_columns(int32_t chain, int32_t camera_model); /* tangent columns per observation:

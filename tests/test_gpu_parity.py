@@ -983,3 +983,12 @@ def test_hip_graph_replay_of_the_lm_stages_equals_plain_launches(gpu_lib, kind, 
         assert a[0] == b[0] and a[1] == b[1]
         assert np.array_equal(a[2], b[2])
         assert (a[3] is None and b[3] is None) or np.array_equal(a[3], b[3])
+
+
+def test_default_device_of_the_handle_less_entry_points(gpu_lib):
+    """cba_set_device / cba_get_device: the device of the one-shot and batched entry points (one process per GPU sets its own)."""
+    assert gpu_lib.cba_get_device() == 0
+    capi.check(gpu_lib, gpu_lib.cba_set_device(0))
+    n = gpu_lib.cba_device_count()
+    assert gpu_lib.cba_set_device(n) == capi.CBA_ERR_INVALID_ARGUMENT and gpu_lib.cba_get_device() == 0
+    assert gpu_lib.cba_set_device(-1) == capi.CBA_ERR_INVALID_ARGUMENT
