@@ -273,6 +273,29 @@ int hm_reproj_block_normal_eq(const cba_reproj_problem* d, int moments, double* 
     });
 }
 
+// build_structure's validation alone (have_records: the observations arrive as per-block records, cba_reproj_create_aos)
+int hm_structure_check(const cba_reproj_problem* d, int have_records) {
+    return guarded([&] {
+        Structure s;
+        build_structure(*d, s, have_records != 0);
+    });
+}
+
+// the constant / gauge masks LMDriver hands to a solver that runs the iteration itself (resident_lm.hip): active[nsh], cam_var[n_cams],
+// flags[3] = {intr_var, target_var, constrained}
+int hm_reproj_masks(const cba_reproj_problem* d, const cba_options* o, int8_t* active, int8_t* cam_var, int32_t* flags) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+        const LMDriver::Masks m = drv.masks(*o);
+        for (int i = 0; i < ss.s.nsh; ++i) active[i] = m.active[i];
+        for (int c = 0; c < ss.s.n_cams; ++c) cam_var[c] = m.cam_var[c];
+        flags[0] = m.intr_var; flags[1] = m.target_var; flags[2] = m.constrained;
+    });
+}
+
 int64_t hm_reproj_covariance_dim(const cba_reproj_problem* d) {
     Session ss;
     try { load(*d, ss); } catch (...) { return -1; }

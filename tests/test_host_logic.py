@@ -728,3 +728,42 @@ def test_axxb_pair_partition_over_ranks_tiles_and_balances(hostmath, n, world):
     total = n * (n - 1) // 2
     assert sum(pairs) == total
     assert max(pairs) <= total / world + (n - 1)
+
+
+def test_structure_validation_with_observation_records(hostmath):
+    """cba_reproj_create_aos hands build_structure a problem WITHOUT flat X, Y, u, v arrays: valid only in the records form."""
+    sc = synth.scene_intrinsics(5)
+    d = sc.flat.struct()
+    assert hostmath.hm_structure_check(C.byref(d), 0) == capi.CBA_OK
+    d.X = d.Y = d.u = d.v = None
+    assert hostmath.hm_structure_check(C.byref(d), 0) == capi.CBA_ERR_INVALID_ARGUMENT
+    assert hostmath.hm_structure_check(C.byref(d), 1) == capi.CBA_OK
+    d.blk_offset = None
+    assert hostmath.hm_structure_check(C.byref(d), 1) == capi.CBA_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("kind,okw,expect", [
+    ("intr", dict(optimize_skew=0), dict(n_active=9, intr_var=1, target_var=0, constrained=1)),
+    ("intr", dict(optimize_skew=1), dict(n_active=10, intr_var=1, target_var=0, constrained=1)),
+    ("ext", dict(optimize_intrinsics=0, optimize_extrinsics=1), dict(n_active=6, intr_var=0, target_var=0, constrained=0)),
+    ("ext", dict(optimize_intrinsics=1, optimize_extrinsics=0), dict(n_active=18, intr_var=1, target_var=0, constrained=1)),
+    ("bundle", dict(optimize_intrinsics=0, optimize_extrinsics=1, optimize_target_pose=1), dict(n_active=12, intr_var=0, target_var=1, constrained=0)),
+    ("bundle", dict(optimize_intrinsics=1, optimize_extrinsics=0, optimize_target_pose=0), dict(n_active=9, intr_var=1, target_var=0, constrained=1)),
+])
+def test_masks_handed_to_the_resident_solver(hostmath, kind, okw, expect):
+    """LMDriver::masks — what resident_lm.hip receives instead of running the driver: which reduced columns Ceres would hold
+    constant (constant blocks, skew subset, gauge camera 0: intrinsics.cpp:70-87, extrinsics.cpp:110-150, bundle.cpp:98-131)."""
+    sc = {"intr": lambda: synth.scene_intrinsics(5), "ext": lambda: synth.scene_extrinsics(4, 2),
+          "bundle": lambda: synth.scene_bundle(6, 1)}[kind]()
+    d = sc.flat.struct()
+    nsh = {"intr": 10, "ext": 2 * 16, "bundle": 6 + 16}[kind]
+    active = np.zeros(nsh, np.int8)
+    cam_var = np.zeros(sc.flat.n_cams, np.int8)
+    flags = np.zeros(3, np.int32)
+    o = options(**okw)
+    assert hostmath.hm_reproj_masks(C.byref(d), C.byref(o), active.ctypes.data_as(C.POINTER(C.c_int8)),
+                                    cam_var.ctypes.data_as(C.POINTER(C.c_int8)), flags.ctypes.data_as(C.POINTER(C.c_int32))) == capi.CBA_OK
+    assert int(active.sum()) == expect["n_active"]
+    assert [int(x) for x in flags] == [expect["intr_var"], expect["target_var"], expect["constrained"]]
+    if kind == "ext":
+        assert cam_var[0] == 0  # camera 0 is the gauge
