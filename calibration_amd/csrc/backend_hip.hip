@@ -174,9 +174,14 @@ __device__ __forceinline__ void schur_gvec_chunk(const SchurDims& d, int n_views
                                                  const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ out) {
     const int v1 = min(n_views, v0 + VCHUNK);
     for (int g = threadIdx.x; g < nsh; g += blockDim.x) {
+        const int cam = g / d.PC, lc = g - cam * d.PC;  // (z_entry's decode, hoisted out of the view loop)
         double s = 0.0;
-        for (int v = v0; v < v1; ++v)
-            for (int k = 0; k < 6; ++k) s += z_entry(d, view_cam_blk, blk_Z, v, g, k, nsh) * y[6 * static_cast<int64_t>(v) + k];
+        for (int v = v0; v < v1; ++v) {
+            const int b = view_cam_blk[static_cast<int64_t>(v) * d.n_cams + cam];
+            if (b < 0) continue;
+            const double* z = blk_Z + static_cast<int64_t>(b) * 6 * d.PSH + lc;
+            for (int k = 0; k < 6; ++k) s += z[k * d.PSH] * y[6 * static_cast<int64_t>(v) + k];
+        }
         out[g] = s;
     }
 }
