@@ -553,26 +553,6 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
             last = t;
         }
     };
-    auto new_system = [&](bool init_scale) {
-        phase_consts<CHAIN, MODEL>(a, sh, 0);
-        tick(0);
-        phase_mode_b<CHAIN, MODEL>(a);
-        tick(1);
-        const double cost = phase_weights(a, sh);
-        tick(2);
-        phase_assemble(a, init_scale, sh);
-        tick(3);
-        phase_schur(a, init_scale, sh, tick);
-        tick(4);
-        const double gm_shared = shared_gmax(a, sh);
-        if (tid == 0) {
-            sh.cost = cost;
-            sh.gmax = fmax(sh.gmax_priv, gm_shared);
-        }
-        __syncthreads();
-        tick(5);
-    };
-
     {
         const int PI = IntrSize<MODEL>::value;
         for (int i = tid; i < a.n_cams * PI; i += RES_THREADS) {
@@ -592,96 +572,119 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
         __syncthreads();
         publish_shared(a, sh, 0, 0);
     }
-    new_system(true);
-    const double initial_cost = sh.cost;
+    double initial_cost = 0.0;
     int iter = 0, invalid = 0, successful = 0, term = CBA_TERM_FAILURE, msg = MSG_INVALID_STEPS;
-
-    if (sh.gmax <= eps) {
-        term = CBA_TERM_CONVERGENCE; msg = MSG_GRADIENT;
-    } else {
-        while (true) {  // every condition below is workgroup-uniform (read from LDS after a barrier)
-            if (iter >= a.max_iterations) { term = CBA_TERM_NO_CONVERGENCE; msg = MSG_MAX_ITER; break; }
+    // One loop, every phase once in the code (the kernel is ~15 000 instructions; inlining the linearisation at each of its call
+    // sites doubled that): a pass starts with a new linearisation at copy 0 (`linearise`: first pass and after an accepted step)
+    // or with the per-view elimination alone at the new radius (`re_eliminate`: after a rejected or invalid step).
+    bool linearise = true, re_eliminate = false, first = true;
+    while (true) {  // every condition below is workgroup-uniform (read from LDS after a barrier)
+        if (linearise) {
+            phase_consts<CHAIN, MODEL>(a, sh, 0);
+            tick(0);
+            phase_mode_b<CHAIN, MODEL>(a);
+            tick(1);
+            const double cost = phase_weights(a, sh);
+            tick(2);
+            phase_assemble(a, first, sh);
+            tick(3);
+            if (tid == 0) sh.cost = cost;
+        }
+        if (linearise || re_eliminate) {
+            phase_schur(a, first && linearise, sh, tick);
+            tick(4);
+        }
+        if (linearise) {
+            const double gm_shared = shared_gmax(a, sh);
+            if (tid == 0) sh.gmax = fmax(sh.gmax_priv, gm_shared);
+            __syncthreads();
+            tick(5);
+        }
+        linearise = re_eliminate = false;
+        if (first) {  // (the driver tests the gradient at the start point before it looks at the iteration budget)
+            first = false;
+            initial_cost = sh.cost;
             if (sh.gmax <= eps) { term = CBA_TERM_CONVERGENCE; msg = MSG_GRADIENT; break; }
-            if (sh.radius <= min_radius) { term = CBA_TERM_CONVERGENCE; msg = MSG_MIN_RADIUS; break; }
-            ++iter;
-            tick(10);
-            phase_solve_reduced(a, sh);
-            tick(6);
-            bool valid = sh.valid != 0;
-            if (valid) {
-                // trial point: shared blocks (thread 0), private poses + the views' model terms (one thread per view)
-                // step2, xnorm2, g^T d, d^T H d (shared blocks' and views' shares together), then the shared-shared part of
-                // the model change g_c^T d_c, d_c^T H_cc d_c (computed by the workgroup's LAST threads: the first ones have views)
-                double st[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                shared_plus(a, sh, sh.delta, &st[0], &st[1]);
-                for (int v = tid; v < a.n_views; v += RES_THREADS) {
-                    const int nb = static_cast<int>(a.link_off[v + 1] - a.link_off[v]);
-                    double o4[4];
-                    backsub_view_body(a.dims, nb, a.link_blk + a.link_off[v], a.blk_cam, a.blk_Z, sh.delta, a.view_fixed[v] != 0,
-                                      a.view_L + 36 * static_cast<int64_t>(v), a.view_y + 6 * static_cast<int64_t>(v),
-                                      a.view_D + 6 * static_cast<int64_t>(v), a.view_gp + 6 * static_cast<int64_t>(v),
-                                      a.view[0] + 7 * static_cast<int64_t>(v), a.view_delta + 6 * static_cast<int64_t>(v),
-                                      a.view[1] + 7 * static_cast<int64_t>(v), o4);
-                    for (int k = 0; k < 4; ++k) st[k] += o4[k];
-                }
-                for (int i = RES_THREADS - 1 - tid; i < n; i += RES_THREADS) {
-                    const double di = sh.delta[i];
-                    if (di != 0.0) {
-                        st[4] += sh.gc[i] * di;
-                        double s = 0.0;
-                        for (int j = 0; j < n; ++j) s += a.Hcc[static_cast<int64_t>(i) * n + j] * sh.delta[j];
-                        st[5] += di * s;
-                    }
-                }
-                block_sum(st, sh);
-                tick(7);
-                const double model_change = -(st[2] + st[4]) - 0.5 * (st[3] + st[5]);
-                if (!(model_change > 0.0) || !(fabs(model_change) <= 1.7976931348623157e308)) valid = false;
-                if (valid) {
-                    publish_shared(a, sh, 1, 1, /*barrier=*/false);  // (from == to in LDS: only the global copies change)
-                    phase_consts<CHAIN, MODEL>(a, sh, 1);
-                    double cand = phase_resid_cost<MODEL>(a, 1, sh);
-                    tick(8);
-                    if (!(fabs(cand) <= 1.7976931348623157e308)) cand = 1.7976931348623157e308;
-                    const double step_norm = sqrt(st[0]), x_norm = sqrt(st[1]);
-                    if (step_norm <= eps * (x_norm + eps)) { term = CBA_TERM_CONVERGENCE; msg = MSG_PARAMETER; break; }
-                    const double cost_change = sh.cost - cand;
-                    if (fabs(cost_change) <= eps * sh.cost) { term = CBA_TERM_CONVERGENCE; msg = MSG_FUNCTION; break; }
-                    const double rel = cost_change / model_change;
-                    invalid = 0;
-                    if (rel > min_rel_decrease) {
-                        // accept: copy 1 -> copy 0
-                        publish_shared(a, sh, 1, 0);
-                        for (int i = tid; i < a.n_views * 7; i += RES_THREADS) a.view[0][i] = a.view[1][i];
-                        ++successful;
-                        __syncthreads();
-                        if (tid == 0) {
-                            const double t = 2.0 * rel - 1.0;
-                            sh.radius = fmin(max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                            sh.decrease_factor = 2.0;
-                        }
-                        __syncthreads();
-                        tick(9);
-                        new_system(false);
-                    } else {
-                        __syncthreads();
-                        if (tid == 0) {
-                            sh.radius = sh.radius / sh.decrease_factor;
-                            sh.decrease_factor *= 2.0;
-                        }
-                        __syncthreads();
-                        phase_schur(a, false, sh, tick);
-                    }
-                    continue;
+        }
+        if (iter >= a.max_iterations) { term = CBA_TERM_NO_CONVERGENCE; msg = MSG_MAX_ITER; break; }
+        if (sh.gmax <= eps) { term = CBA_TERM_CONVERGENCE; msg = MSG_GRADIENT; break; }
+        if (sh.radius <= min_radius) { term = CBA_TERM_CONVERGENCE; msg = MSG_MIN_RADIUS; break; }
+        ++iter;
+        tick(10);
+        phase_solve_reduced(a, sh);
+        tick(6);
+        bool valid = sh.valid != 0;
+        if (valid) {
+            // trial point: step2, xnorm2, g^T d, d^T H d (shared blocks' and views' shares together), then the shared-shared part
+            // of the model change g_c^T d_c, d_c^T H_cc d_c (computed by the workgroup's LAST threads: the first ones have views)
+            double st[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            shared_plus(a, sh, sh.delta, &st[0], &st[1]);
+            for (int v = tid; v < a.n_views; v += RES_THREADS) {
+                const int nb = static_cast<int>(a.link_off[v + 1] - a.link_off[v]);
+                double o4[4];
+                backsub_view_body(a.dims, nb, a.link_blk + a.link_off[v], a.blk_cam, a.blk_Z, sh.delta, a.view_fixed[v] != 0,
+                                  a.view_L + 36 * static_cast<int64_t>(v), a.view_y + 6 * static_cast<int64_t>(v),
+                                  a.view_D + 6 * static_cast<int64_t>(v), a.view_gp + 6 * static_cast<int64_t>(v),
+                                  a.view[0] + 7 * static_cast<int64_t>(v), a.view_delta + 6 * static_cast<int64_t>(v),
+                                  a.view[1] + 7 * static_cast<int64_t>(v), o4);
+                for (int k = 0; k < 4; ++k) st[k] += o4[k];
+            }
+            for (int i = RES_THREADS - 1 - tid; i < n; i += RES_THREADS) {
+                const double di = sh.delta[i];
+                if (di != 0.0) {
+                    st[4] += sh.gc[i] * di;
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s += a.Hcc[static_cast<int64_t>(i) * n + j] * sh.delta[j];
+                    st[5] += di * s;
                 }
             }
-            // invalid step: the linear solve failed or the model did not decrease
-            if (++invalid >= 5) { term = CBA_TERM_FAILURE; msg = MSG_INVALID_STEPS; break; }
-            __syncthreads();
-            if (tid == 0) sh.radius *= 0.5;
-            __syncthreads();
-            phase_schur(a, false, sh, tick);
+            block_sum(st, sh);
+            tick(7);
+            const double model_change = -(st[2] + st[4]) - 0.5 * (st[3] + st[5]);
+            if (!(model_change > 0.0) || !(fabs(model_change) <= 1.7976931348623157e308)) valid = false;
+            if (valid) {
+                publish_shared(a, sh, 1, 1, /*barrier=*/false);  // (from == to in LDS: only the global copies change)
+                phase_consts<CHAIN, MODEL>(a, sh, 1);
+                double cand = phase_resid_cost<MODEL>(a, 1, sh);
+                tick(8);
+                if (!(fabs(cand) <= 1.7976931348623157e308)) cand = 1.7976931348623157e308;
+                const double step_norm = sqrt(st[0]), x_norm = sqrt(st[1]);
+                if (step_norm <= eps * (x_norm + eps)) { term = CBA_TERM_CONVERGENCE; msg = MSG_PARAMETER; break; }
+                const double cost_change = sh.cost - cand;
+                if (fabs(cost_change) <= eps * sh.cost) { term = CBA_TERM_CONVERGENCE; msg = MSG_FUNCTION; break; }
+                const double rel = cost_change / model_change;
+                invalid = 0;
+                if (rel > min_rel_decrease) {  // accept: copy 1 -> copy 0, new linearisation next
+                    publish_shared(a, sh, 1, 0);
+                    for (int i = tid; i < a.n_views * 7; i += RES_THREADS) a.view[0][i] = a.view[1][i];
+                    ++successful;
+                    __syncthreads();
+                    if (tid == 0) {
+                        const double t = 2.0 * rel - 1.0;
+                        sh.radius = fmin(max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                        sh.decrease_factor = 2.0;
+                    }
+                    __syncthreads();
+                    tick(9);
+                    linearise = true;
+                } else {  // reject: shrink the radius, eliminate again
+                    __syncthreads();
+                    if (tid == 0) {
+                        sh.radius = sh.radius / sh.decrease_factor;
+                        sh.decrease_factor *= 2.0;
+                    }
+                    __syncthreads();
+                    re_eliminate = true;
+                }
+                continue;
+            }
         }
+        // invalid step: the linear solve failed or the model did not decrease
+        if (++invalid >= 5) { term = CBA_TERM_FAILURE; msg = MSG_INVALID_STEPS; break; }
+        __syncthreads();
+        if (tid == 0) sh.radius *= 0.5;
+        __syncthreads();
+        re_eliminate = true;
     }
     __syncthreads();
     phase_consts<CHAIN, MODEL>(a, sh, 0);  // leave bc / sd at the accepted point
