@@ -69,18 +69,6 @@ inline void fill_core(const cba_summary& s, const cba_options& o, const std::vec
     }
 }
 
-    std::vector<int32_t> cam, view;
-    std::vector<double> bTg;
-    void push(const calib::PlanarView& pv, int c, int vw) {
-        for (const auto& ob : pv) {
-            X.push_back(ob.object_xy.x()); Y.push_back(ob.object_xy.y());
-            u.push_back(ob.image_uv.x()); v.push_back(ob.image_uv.y());
-        }
-        off.push_back(static_cast<int64_t>(X.size()));
-        cam.push_back(c); view.push_back(vw);
-    }
-};
-
 // The reference's PlanarObservation {Eigen::Vector2d object_xy, image_uv} (linear/planarpose.h:22-26) is four contiguous
 // doubles, so a PlanarView's storage IS the {X, Y, u, v} record array cba_reproj_create_aos reads in place: the three
 // reprojection solvers below never copy an observation on the host.

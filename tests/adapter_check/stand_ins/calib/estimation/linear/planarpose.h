@@ -1,0 +1,2 @@
+#pragma once
+#include "../../../calib_min.h"  // test-only stand-in, see calib_min.h
