@@ -161,6 +161,7 @@ static void drive_extrinsics(const char* name) {
     std::vector<CameraT> cams(2, make_camera<CameraT>(init));
     std::vector<Isometry3d> ic = {c_T_r[0], mul(make_pose(1, 0, 1, 0.01, 0.003, 0.001, -0.002), c_T_r[1])}, it;
     for (const auto& T : r_T_t) it.push_back(mul(make_pose(0, 1, 1, 0.008, -0.002, 0.001, 0.003), T));
+    it[0] = r_T_t[0];  // the first target pose is held constant when intrinsics are optimised (extrinsics.cpp:123-126)
     calib::ExtrinsicOptions opts;
     opts.core.epsilon = 1e-12;
     auto res = ad::optimize_extrinsics(views, cams, ic, it, opts);

@@ -246,10 +246,11 @@ def test_mirror_api_end_to_end(gpu_lib):
 
 
 # ---- AX = XB on the GPU ------------------------------------------------------------------------------
-def test_reference_kat_axxb_on_gpu(gpu_lib):
+@pytest.mark.parametrize("name", ["axxb_refine", "stdrng/axxb_refine"])
+def test_reference_kat_axxb_on_gpu(gpu_lib, name):
     from calibration_amd.geometry import rotation_angle
 
-    sc = kat.KAT["axxb_refine"]
+    sc = kat.KAT[name]
     X_gt, X0 = np.asarray(sc["X_gt"]), np.asarray(sc["X_init"])
     res = optim.optimize_handeye([np.asarray(T) for T in sc["b_T_g"]], [np.asarray(T) for T in sc["c_T_t"]], X0,
                                  optim.OptimOptions(optimizer=3, max_iterations=60, huber_delta=1.0))
