@@ -6,8 +6,10 @@ Workload (BASELINE.json configs[1]): pinhole + Brown-Conrady intrinsics refineme
 2-vector residual and the 2x16 tangent-space Jacobian of every observation of this rank's views are
 produced and written to HBM, inputs already resident.  With N > 1 ranks each rank owns 1000 views of
 an N*1000-view problem (weak scaling, views sharded, no data-path collective inside the pass); the
-one real exchange of the path — the sum-all-reduce of the reduced normal equations per LM linear
-solve — is exercised by the LM solve reported under "lm" (RCCL over xGMI).
+one real exchange of the path — the sum-all-reduce of the packed reduced normal equations, one per LM
+step — is exercised by the LM solves reported under "lm" (this workload, weak) and "lm_strong"
+(BASELINE configs[2], the 8-camera extrinsic bundle of 1.6e8 observations split over the N ranks: the
+north-star's obs-sharded strong-scaling case; wall clock, collective count and bytes), RCCL over xGMI.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
 """
@@ -36,6 +38,7 @@ def main():
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lm-timeout", type=float, default=240.0, help="watchdog for the LM section, seconds")
+    ap.add_argument("--c3-views", type=int, default=4000, help="views of the strong-scaling problem (BASELINE configs[2]: 4000), split over the ranks; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,60 +118,106 @@ def main():
                 "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
     # ---- Mode B (per-block normal equations, the kernel that sets the LM wall clock): fp64-issue bound ----------------
-    # operations per observation counted from the kernel source: 225 fused accumulate operations for the
-    # whole [H | g | s] row + 2 launches x ~110 for the residual / Jacobian rows; FMA = 2 FLOP, vector fp64 peak 78.6 TFLOP/s
+    # FLOPs counted from the ISA of the two launches' hot loops (tools/isa_mix.py on the shipped kernels, FMA = 2, mul / add = 1;
+    # profiles/r02_modeb_isa_mix.txt): per observation and launch 159 FMA + 81 mul/add = 399 FLOP ISSUED, of which 113 FMA are
+    # the launch's share of the 225 accumulate operations of [H | g | s] and the rest is the residual / Jacobian row evaluation,
+    # which BOTH launches repeat.  USEFUL work = 225 accumulate FMAs + one row evaluation = 450 + 173 FLOP.
     ms_b = h.normal_eq_timed(2, 10)
-    ops_b = 225 + 2 * 110
+    flop_issued, flop_useful = 2 * 399, 450 + 173
     mode_b = {"kernel": "k_normal_eq<INTRINSIC,PINHOLE_BC> x2 + k_tile_sum", "ms_per_pass": ms_b, "bound": "fp64 vector issue",
-              "fp64_ops_per_obs": ops_b, "achieved_TFLOPs": 2 * ops_b * n_obs / (ms_b * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
-              "frac": 2 * ops_b * n_obs / (ms_b * 1e-3) / 78.6e12, "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
+              "flop_per_obs_issued": flop_issued, "flop_per_obs_useful": flop_useful,
+              "issued_TFLOPs": flop_issued * n_obs / (ms_b * 1e-3) / 1e12, "useful_TFLOPs": flop_useful * n_obs / (ms_b * 1e-3) / 1e12,
+              "peak_TFLOPs": 78.6, "frac_issued": flop_issued * n_obs / (ms_b * 1e-3) / 78.6e12,
+              "frac_useful": flop_useful * n_obs / (ms_b * 1e-3) / 78.6e12, "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path
     # cannot be rehearsed on a 1-GPU box) must not swallow the evals/s line measured above.
     lm_box = {}
 
+    def setup_transport(handle):
+        if world > 1 and dist.get_backend() != "nccl":  # rehearsal: host-callback transport over the CPU backend
+            def _allreduce(arr):
+                dist.all_reduce(torch.from_numpy(arr))
+            handle.set_allreduce(_allreduce, world, rank)
+            return f"host callback over torch.distributed {dist.get_backend()} (rehearsal)"
+        if world > 1:
+            try:  # RCCL-native: ncclAllReduce of the device-resident packed system on the engine's stream
+                uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid = torch.tensor(list(optim.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+                dist.broadcast(uid, 0)
+                handle.init_rccl(bytes(uid.cpu().numpy().tolist()), world, rank)
+                return "rccl (libcalibba ncclAllReduce, device-resident pack)"
+            except Exception as ex:  # fall back to the host-callback transport over torch.distributed (RCCL)
+                def _allreduce(arr):
+                    t = torch.from_numpy(arr).cuda()
+                    dist.all_reduce(t)
+                    arr[...] = t.cpu().numpy()
+                handle.set_allreduce(_allreduce, world, rank)
+                return f"host callback over torch.distributed nccl ({type(ex).__name__})"
+        return "none (1 rank)"
+
+    def timed_solve(handle):
+        o = capi.default_options()
+        o.compute_covariance = 0
+        barrier()
+        t1 = time.perf_counter()
+        s = handle.solve(o)
+        barrier()
+        wall = time.perf_counter() - t1
+        if dist is not None:  # the slowest rank's clock
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return s, wall
+
     def run_lm():
         try:
             torch.cuda.set_device(local_rank)
-            if world > 1 and dist.get_backend() != "nccl":  # rehearsal: host-callback transport over the CPU backend
-                def _allreduce(arr):
-                    dist.all_reduce(torch.from_numpy(arr))
-                h.set_allreduce(_allreduce, world, rank)
-                transport = f"host callback over torch.distributed {dist.get_backend()} (rehearsal)"
-            elif world > 1:
-                try:  # RCCL-native: ncclAllReduce of the packed reduced system on the engine's stream
-                    uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-                    if rank == 0:
-                        uid = torch.tensor(list(optim.rccl_unique_id()), dtype=torch.uint8, device="cuda")
-                    dist.broadcast(uid, 0)
-                    h.init_rccl(bytes(uid.cpu().numpy().tolist()), world, rank)
-                    transport = "rccl (libcalibba ncclAllReduce)"
-                except Exception as ex:  # fall back to the host-callback transport over torch.distributed (RCCL)
-                    def _allreduce(arr):
-                        t = torch.from_numpy(arr).cuda()
-                        dist.all_reduce(t)
-                        arr[...] = t.cpu().numpy()
-                    h.set_allreduce(_allreduce, world, rank)
-                    transport = f"host callback over torch.distributed nccl ({type(ex).__name__})"
-            else:
-                transport = "none (1 rank)"
+            transport = setup_transport(h)
             h.set_params(intr=init_intr, view_pose=init_view)
-            o = capi.default_options()
-            o.compute_covariance = 0
-            barrier()
-            t1 = time.perf_counter()
-            s = h.solve(o)
-            barrier()
-            lm_s = time.perf_counter() - t1
+            s, lm_s = timed_solve(h)
+            xs = h.solve_stats()
             lm_box["lm"] = {"wall_s": lm_s, "iterations": int(s.iterations), "success": bool(s.success),
                             "final_cost": float(s.final_cost),
                             "intr_err_max": float(np.abs(flat.intr - scene.gt_intr).max()), "views_total": world * args.views,
-                            "obs_total": world * n_obs, "allreduce": transport}
+                            "obs_total": world * n_obs, "allreduce": transport, "allreduce_calls": xs["allreduce_calls"],
+                            "allreduce_bytes": 8 * xs["allreduce_doubles"], "accepted_steps": int(s.successful_steps),
+                            "speculation": {k: xs[k] for k in ("speculative_steps", "speculation_hits", "speculation_misses", "rejected_steps")}}
         except Exception as ex:  # the evals/s line must still be printed
             lm_box["lm"] = {"error": f"{type(ex).__name__}: {ex}"}
+            return
+        # ---- STRONG scaling of the LM (the north-star's obs-sharded case): BASELINE configs[2], 8-camera extrinsic bundle,
+        # c3_views x 8 x 5000 observations in total, views split over the ranks, one packed all-reduce per LM step ----------------
+        if args.c3_views <= 0:
+            return
+        try:
+            v0, v1 = rank * args.c3_views // world, (rank + 1) * args.c3_views // world
+            t2 = time.time()
+            sc3 = synth.scene_extrinsics_shard(args.c3_views, v0, v1)
+            gen3 = time.time() - t2
+            with optim.ReprojHandle(sc3.flat, device=local_rank) as h3:
+                transport3 = setup_transport(h3)
+                start = (sc3.flat.intr.copy(), sc3.flat.cam_pose.copy(), sc3.flat.view_pose.copy())
+                s3, wall3 = timed_solve(h3)  # first solve on the handle
+                h3.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
+                s3, wall3b = timed_solve(h3)
+                xs3 = h3.solve_stats()
+                ms_b3 = h3.normal_eq_timed(1, 3)
+            obs_total = args.c3_views * 8 * 5000
+            lm_box["lm_strong"] = {"workload": f"8-camera extrinsic bundle, {args.c3_views} views x 8 cameras x 5000 pts = {obs_total:.3g} observations "
+                                               f"in total, views split over {world} rank(s) (BASELINE configs[2])",
+                                   "scaling": "strong", "wall_s": min(wall3, wall3b), "wall_first_s": wall3, "iterations": int(s3.iterations),
+                                   "accepted_steps": int(s3.successful_steps), "success": bool(s3.success), "final_cost": float(s3.final_cost),
+                                   "intr_err_max": float(np.abs(sc3.flat.intr - sc3.gt_intr)[:, :4].max()), "allreduce": transport3,
+                                   "allreduce_calls": xs3["allreduce_calls"], "allreduce_bytes": 8 * xs3["allreduce_doubles"],
+                                   "speculation": {k: xs3[k] for k in ("speculative_steps", "speculation_hits", "speculation_misses", "rejected_steps")},
+                                   "mode_b_ms_per_pass_this_rank": ms_b3, "obs_this_rank": int(sc3.flat.n_obs), "scene_gen_s": gen3}
+        except Exception as ex:
+            lm_box["lm_strong"] = {"error": f"{type(ex).__name__}: {ex}"}
 
-    lm, lm_hung = None, False
+    lm, lm_strong, lm_hung = None, None, False
     if not args.no_lm:
         import threading
 
@@ -176,7 +225,8 @@ def main():
         th.start()
         th.join(args.lm_timeout)
         lm_hung = th.is_alive()
-        lm = {"error": f"LM solve did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else lm_box.get("lm")
+        lm = lm_box.get("lm") or ({"error": f"LM solve did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else None)
+        lm_strong = lm_box.get("lm_strong") or ({"error": f"did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else None)
 
     # ---- BASELINE.json configs[0] (20 views x 88 points, the reference's own test size), rank 0 only: the whole LM as one
     # resident single-workgroup kernel launch (resident_lm.hip) and the complete call the reference's pipeline makes
@@ -246,12 +296,13 @@ def main():
             "cpu_baseline": cpu,
             "mode_b": mode_b,
             "lm": lm,
+            "lm_strong": lm_strong,
             "lm_c1": lm_c1,
             "scene_gen_s": t_gen,
         }
         print(json.dumps(out), flush=True)
-    if lm_hung:  # a stuck collective cannot be cancelled: leave without touching the GPU again
-        os._exit(0)
+    if lm_hung:  # a stuck collective cannot be cancelled: the metric line is out; leave without touching the GPU again, and
+        os._exit(3)  # not as a success
     h.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -146,6 +146,7 @@ PROTOTYPES = {
     "cba_reproj_num_observations": (C.c_int64, [C.c_void_p]),
     "cba_reproj_eval": (C.c_int32, [C.c_void_p]),
     "cba_reproj_eval_fetch": (C.c_int32, [C.c_void_p, c_double_p, c_double_p]),
+    "cba_reproj_eval_fetch_blocks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p]),
     "cba_reproj_eval_timed": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
     "cba_reproj_normal_eq_timed": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
     "cba_reproj_set_scalar": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -155,6 +156,7 @@ PROTOTYPES = {
     "cba_reproj_block_normal_eq_size": (C.c_int64, [C.c_void_p]),
     "cba_reproj_solve": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), C.POINTER(CbaSummary)]),
     "cba_reproj_set_lm_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "cba_reproj_solve_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
     "cba_reproj_covariance_dim": (C.c_int64, [C.c_void_p]),
     "cba_reproj_covariance": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), c_double_p]),
     "cba_reproj_covariance_shared_dim": (C.c_int64, [C.c_void_p]),

@@ -307,6 +307,52 @@ __global__ void k_accept(int64_t n_shared, const double* __restrict__ shared_tri
     if (i < n_view) view_cur[i] = view_trial[i];
 }
 
+// The packed exchange buffer of one linear solve (lm_core.hpp PackLayout), assembled ON THE DEVICE: the camera sums are written
+// in place by k_seg_sum; this kernel adds the step statistics, the cost, the dense S_schur unpacked from the syrk tiles, g_schur,
+// the failure count and this rank's gradient-max slot (the other ranks' slots are zeroed: the all-reduce is a sum).
+struct PackArgs {
+    int64_t off_stats, off_cam, off_cost, off_nfail, off_S, off_g, off_gmax;
+    int n, n_tiles, n_ranks, rank, n_cam_doubles;
+    int has_blocks, has_schur, has_stats;
+};
+__global__ __launch_bounds__(256) void k_pack(PackArgs a, const double* __restrict__ stat /*[0..4): step2, xnorm2, gd, dHd; [4]: cost*/,
+                                              const double* __restrict__ tiles /*[pairs*4096 | g | gmax, nfail]*/, double* __restrict__ pack) {
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t nn = static_cast<int64_t>(a.n) * a.n;
+    const int64_t sw = static_cast<int64_t>(a.n_tiles) * (a.n_tiles + 1) / 2 * 4096;
+    if (tid < nn) {
+        const int i = static_cast<int>(tid / a.n), j = static_cast<int>(tid % a.n);
+        double val = 0.0;
+        if (a.has_schur) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int ti = lo >> 6, tj = hi >> 6;
+            const int pair = ti * a.n_tiles - ti * (ti - 1) / 2 + (tj - ti);  // upper-triangular tile pairs in (ti, tj >= ti) order
+            val = tiles[static_cast<int64_t>(pair) * 4096 + (lo & 63) * 64 + (hi & 63)];
+        }
+        pack[a.off_S + tid] = val;
+    }
+    if (tid < a.n) pack[a.off_g + tid] = a.has_schur ? tiles[sw + tid] : 0.0;
+    if (tid < a.n_ranks) pack[a.off_gmax + tid] = (a.has_schur && tid == a.rank) ? tiles[sw + a.n] : 0.0;
+    if (tid == 0) {
+        pack[a.off_nfail] = a.has_schur ? tiles[sw + a.n + 1] : 0.0;
+        pack[a.off_cost] = a.has_blocks ? stat[4] : 0.0;
+        pack[a.off_stats + 0] = a.has_stats ? stat[2] : 0.0;  // PackLayout::GD
+        pack[a.off_stats + 1] = a.has_stats ? stat[3] : 0.0;  // DHD
+        pack[a.off_stats + 2] = a.has_stats ? stat[0] : 0.0;  // STEP2
+        pack[a.off_stats + 3] = a.has_stats ? stat[1] : 0.0;  // XNORM2
+        pack[a.off_stats + 4] = (a.has_stats && a.has_blocks) ? stat[4] : 0.0;  // TRIAL_COST
+    }
+    if (!a.has_blocks && tid < a.n_cam_doubles) pack[a.off_cam + tid] = 0.0;
+}
+
+// an accepted SPECULATIVE step: besides the parameter copies, the trial linearisation's block sums and weights become current
+__global__ void k_accept_blocks(int64_t n_acc, const double* __restrict__ acc_trial, double* __restrict__ acc_cur, int64_t n_w,
+                                const double* __restrict__ w_trial, double* __restrict__ w_cur) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n_acc) acc_cur[i] = acc_trial[i];
+    if (i < n_w) w_cur[i] = w_trial[i];
+}
+
 static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(std::max<int64_t>(1, (n + per - 1) / per)); }
 
 // ---- Backend on an Engine (state: lm_state.hpp) -------------------------------------------------------
@@ -385,15 +431,18 @@ struct HipBackend final : Backend {
         cost2[0] = cost2[1] = 0.0;
         return s.n_blocks != 0;
     }
-    void enqueue_normal_eq(double huber) {
+    // which: parameter copy to linearise at; cam_out [n_cams][NACC] and cost_out {cost, sum s} may be device or page-locked host memory
+    void enqueue_normal_eq(double huber, int which = 0, double* cam_out = nullptr, double* cost_out = nullptr) {
         const Structure& s = st.s;
-        launch_block_consts(e, 0);
-        launch_normal_eq(e);
         const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
+        if (!cam_out) cam_out = st.pin_ne.p;
+        if (!cost_out) cost_out = st.pin_ne.p + nca;
+        launch_block_consts(e, which);
+        launch_normal_eq(e);
         const bool fused_cost = s.n_blocks <= 4096;
         if (fused_cost)
             hipLaunchKernelGGL(k_weights_cost, dim3(1), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL, e.blk_acc.p, huber,
-                               e.blk_w.p, e.blk_s.p, st.pin_ne.p + nca);
+                               e.blk_w.p, e.blk_s.p, cost_out);
         else
             hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL,
                                e.blk_acc.p, huber, e.blk_w.p, e.blk_s.p);
@@ -401,8 +450,8 @@ struct HipBackend final : Backend {
                            st.cam_blk.p, e.blk_w.p, e.blk_acc.p, st.cam_partial.p);
         // the stage's results are written straight into page-locked host memory (device-visible): no copy command on the stream
         hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
-                           s.NACC, st.cam_seg.p, st.cam_partial.p, st.pin_ne.p);
-        if (!fused_cost) launch_cost(e, huber, st.pin_ne.p + nca);
+                           s.NACC, st.cam_seg.p, st.cam_partial.p, cam_out);
+        if (!fused_cost) launch_cost(e, huber, cost_out);
         CBA_HIP(hipGetLastError());
     }
     void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
@@ -423,12 +472,13 @@ struct HipBackend final : Backend {
         st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
         return true;
     }
-    void enqueue_schur(bool constrained) {
+    // which: private pose copy the elimination is made at; tiles_out [syrk tiles | g_schur | gmax, #failed] device or page-locked
+    void enqueue_schur(bool constrained, int which = 0, double* tiles_out = nullptr) {
         const Structure& s = st.s;
         const int n = s.nsh;
         hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                            st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
-                           e.view[0].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
+                           e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                            st.view_gmax.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         if (n >= 64 && st.syrk_mfma)
@@ -437,7 +487,7 @@ struct HipBackend final : Backend {
         else
             hipLaunchKernelGGL(k_schur_syrk, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
                                st.view_cam_blk.p, e.blk_Z.p, e.view_y.p, st.syrk_partial.p);
-        double* pack = st.pin.p;  // [syrk tiles | g_schur | gmax, #failed views] in page-locked host memory
+        double* pack = tiles_out ? tiles_out : st.pin.p;  // [syrk tiles | g_schur | gmax, #failed views]; default: page-locked host memory
         hipLaunchKernelGGL(k_row_sum, dim3(nblk(sw + n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream, static_cast<int64_t>(st.n_vchunks),
                            sw + n, st.syrk_partial.p, pack);
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 0, st.view_gmax.p, st.view_gmax.p, pack + sw + n);
@@ -496,6 +546,125 @@ struct HipBackend final : Backend {
         if (q1) collect_normal_eq(cam_acc, cost2);
         if (q2) collect_schur(S, g, gmax_priv, nfail);
     }
+    // ---- packed systems (lm_core.hpp): assembled on the device, ONE all-reduce in place on the engine's stream (RCCL), one
+    // device-to-host copy of the reduced buffer, one synchronisation ---------------------------------------------------------------
+    PackArgs pack_args(const PackLayout& L, bool has_blocks, bool has_schur, bool has_stats) const {
+        const Structure& s = st.s;
+        PackArgs a;
+        a.off_stats = L.stats; a.off_cam = L.cam; a.off_cost = L.cost; a.off_nfail = L.nfail; a.off_S = L.S; a.off_g = L.g; a.off_gmax = L.gmax;
+        a.n = s.nsh; a.n_tiles = st.n_tiles; a.n_ranks = L.n_ranks; a.rank = e.rank; a.n_cam_doubles = s.n_cams * s.NACC;
+        a.has_blocks = has_blocks; a.has_schur = has_schur; a.has_stats = has_stats;
+        return a;
+    }
+    void ensure_pack(const PackLayout& L) {
+        if (st.pack_dev.n < static_cast<size_t>(L.size)) {
+            st.pack_dev.alloc(static_cast<size_t>(L.size));
+            st.pack_dev.zero(e.stream);
+            st.sys_tiles.alloc(static_cast<size_t>(st.n_pairs) * 4096 + st.s.nsh + 8);
+            st.stat_dev.alloc(8);
+            st.stat_dev.zero(e.stream);
+        }
+        st.pin_packed.reserve(static_cast<size_t>(L.size));
+    }
+    // Where the pack is assembled: in device memory when RCCL reduces it there in place; otherwise the kernels write it straight
+    // into page-locked host memory (no copy command before the one synchronisation, as the unpacked stages do).
+    double* pack_target() { return e.rccl_comm ? st.pack_dev.p : st.pin_packed.p; }
+    void enqueue_pack(const PackLayout& L, bool has_blocks, bool has_schur, bool has_stats) {
+        const int64_t work = std::max<int64_t>({static_cast<int64_t>(st.s.nsh) * st.s.nsh, static_cast<int64_t>(st.s.n_cams) * st.s.NACC, L.n_ranks, 1});
+        hipLaunchKernelGGL(k_pack, dim3(nblk(work, 256)), dim3(256), 0, e.stream, pack_args(L, has_blocks, has_schur, has_stats),
+                           st.stat_dev.p, st.sys_tiles.p, pack_target());
+        CBA_HIP(hipGetLastError());
+    }
+    // sum [off, off + count) of the packed buffer over the ranks and bring it to `pack` on the host
+    void exchange(int64_t off, int64_t count, const AllReduce& ar, double* pack) {
+        if (e.rccl_comm) {  // RCCL over xGMI, in place on the device buffer, on the engine's stream: no host staging
+            const ncclResult_t r = ncclAllReduce(st.pack_dev.p + off, st.pack_dev.p + off, static_cast<size_t>(count), ncclDouble, ncclSum,
+                                                 reinterpret_cast<ncclComm_t>(e.rccl_comm), e.stream);
+            if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+            ++device_allreduce_calls;
+            device_allreduce_doubles += count;
+            st.pack_dev.download(st.pin_packed.p + off, static_cast<size_t>(count), e.stream, static_cast<size_t>(off));
+        }
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        if (!e.rccl_comm) ar(st.pin_packed.p + off, count);  // host transport (gloo / MPI callback) or a single rank
+        std::memcpy(pack + off, st.pin_packed.p + off, sizeof(double) * static_cast<size_t>(count));
+    }
+    void sys_new(double huber, double radius, bool init_scale, bool constrained, const PackLayout& L, const AllReduce& ar, int rank,
+                 double* pack) override {
+        (void)rank;
+        const Structure& s = st.s;
+        ensure_pack(L);
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        st.pin_lmp.p[0] = radius;
+        st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
+        if (q1) enqueue_normal_eq(huber, 0, pack_target() + L.cam, st.stat_dev.p + 4);
+        if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
+        enqueue_pack(L, q1, q2, false);
+        exchange(L.cam, L.size - L.cam, ar, pack);
+        e.active = 0;
+    }
+    void sys_resolve(double radius, bool constrained, const PackLayout& L, const AllReduce& ar, int rank, double* pack) override {
+        (void)rank;
+        const Structure& s = st.s;
+        ensure_pack(L);
+        const bool q2 = s.n_views != 0;
+        st.pin_lmp.p[0] = radius;
+        st.pin_lmp.p[1] = 0.0;
+        if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
+        enqueue_pack(L, s.n_blocks != 0, q2, false);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
+        exchange(L.nfail, L.gmax - L.nfail, ar, pack);
+    }
+    bool sys_step(const double* delta_sh, double huber, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
+                  int rank, double* pack) override {
+        (void)rank;
+        const Structure& s = st.s;
+        if (e.scalar) return false;  // fp32 study mode keeps the plain sequence
+        ensure_pack(L);
+        if (e.blk_acc_alt.n < e.blk_acc.n) { e.blk_acc_alt.alloc(e.blk_acc.n); e.blk_w_alt.alloc(e.blk_w.n); }
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        std::memcpy(st.pin_pack[1].p + e.pk_delta, delta_sh, sizeof(double) * s.nsh);
+        e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta + static_cast<size_t>(s.nsh), e.stream);  // trial blocks + step
+        if (q2) {  // statistics of the step from the CURRENT factors, trial poses into copy 1
+            hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                               st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
+                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
+                               static_cast<const double*>(nullptr), st.stat_dev.p);
+        } else {
+            CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        }
+        // linearise at the trial point into the second set of block sums / weights; the current set stays valid for a rejected step
+        st.pin_lmp.p[0] = radius_next;
+        st.pin_lmp.p[1] = 0.0;
+        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+        std::swap(e.blk_w.p, e.blk_w_alt.p);
+        try {
+            if (q1) enqueue_normal_eq(huber, 1, pack_target() + L.cam, st.stat_dev.p + 4);
+            if (q2) enqueue_schur(constrained, 1, st.sys_tiles.p);
+        } catch (...) {
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+            throw;
+        }
+        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+        std::swap(e.blk_w.p, e.blk_w_alt.p);
+        enqueue_pack(L, q1, q2, true);
+        exchange(0, L.size, ar, pack);
+        e.active = 1;
+        return true;
+    }
+    void accept_step() override {
+        const int64_t n_shared = static_cast<int64_t>(e.pk_delta), n_view = static_cast<int64_t>(e.h_view.size());
+        hipLaunchKernelGGL(k_accept, dim3(nblk(std::max(n_shared, n_view), 256)), dim3(256), 0, e.stream, n_shared, e.shared_pack[1].p,
+                           e.shared_pack[0].p, n_view, e.view[1].p, e.view[0].p);
+        const int64_t n_acc = static_cast<int64_t>(st.s.n_blocks) * st.s.NACC, n_w = st.s.n_blocks;
+        if (n_acc > 0)
+            hipLaunchKernelGGL(k_accept_blocks, dim3(nblk(n_acc, 256)), dim3(256), 0, e.stream, n_acc, e.blk_acc_alt.p, e.blk_acc.p, n_w,
+                               e.blk_w_alt.p, e.blk_w.p);
+        CBA_HIP(hipGetLastError());
+        e.active = 1;  // bc / sd were built from copy 1 = the values copy 0 now holds
+    }
+
     void trial(const double* delta_sh, double huber, TrialStats* out) override {
         const Structure& s = st.s;
         *out = TrialStats();
@@ -626,6 +795,11 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     CBA_HIP(hipStreamSynchronize(e.stream));
 }
 
+void solve_stats(const Engine& e, int64_t stats6[6]) {
+    const HipLMState* st = reinterpret_cast<const HipLMState*>(e.lm_state);
+    for (int k = 0; k < 6; ++k) stats6[k] = st ? st->xs[k] : 0;
+}
+
 void set_lm_mode(Engine& e, int mode) {
     if (mode < 0 || mode > 2) throw std::invalid_argument("lm mode: 0 host-driven, 1 automatic, 2 resident whenever possible");
     lm_state(e)->resident_mode = mode;
@@ -714,6 +888,22 @@ void warm_lm(Engine& e) {
     be.upload_shared(1, e.h_intr.data(), e.h_cam.data(), e.h_target.data());
     TrialStats ts;
     be.trial(d.data(), 1.0, &ts);
+    {   // the packed forms of the same stages (k_pack, k_accept_blocks) — without a collective: warm-up is per process, not per group
+        const PackLayout L(s, 1);
+        std::vector<double> pack(static_cast<size_t>(L.size), 0.0);
+        const AllReduce none = [](double*, int64_t) {};
+        void* comm = e.rccl_comm;
+        e.rccl_comm = nullptr;
+        be.sys_new(1.0, 1e4, true, false, L, none, 0, pack.data());
+        be.sys_resolve(1e4, false, L, none, 0, pack.data());
+        be.upload_shared(1, e.h_intr.data(), e.h_cam.data(), e.h_target.data());
+        (void)be.sys_step(d.data(), 1.0, 1e4, false, L, none, 0, pack.data());
+        // (the step is NOT accepted: even with a zero shared step the trial poses differ from the current ones; the kernel of
+        // accept_step is set up by an empty launch)
+        hipLaunchKernelGGL(k_accept_blocks, dim3(1), dim3(64), 0, e.stream, static_cast<int64_t>(0), e.blk_acc_alt.p, e.blk_acc.p,
+                           static_cast<int64_t>(0), e.blk_w_alt.p, e.blk_w.p);
+        e.rccl_comm = comm;
+    }
     lm_state(e)->g_new.uses = lm_state(e)->g_schur.uses = lm_state(e)->g_trial.uses = 0;
     CBA_HIP(hipStreamSynchronize(e.stream));
 }
@@ -721,11 +911,18 @@ void warm_lm(Engine& e) {
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
     if (resident_lm_eligible(e, o)) {  // small problem: the whole iteration in one kernel launch
         resident_lm_solve(e, o, out);
+        for (int k = 0; k < 6; ++k) lm_state(e)->xs[k] = 0;
         return;
     }
     HipBackend be(e, *lm_state(e));
     LMDriver drv = make_driver(e, be);
     drv.solve(o, out);
+    {
+        const ExchangeStats& x = drv.exchange_stats();
+        int64_t* xs = lm_state(e)->xs;
+        xs[0] = x.allreduce_calls; xs[1] = x.allreduce_doubles; xs[2] = x.speculative_steps; xs[3] = x.speculation_hits;
+        xs[4] = x.speculation_misses; xs[5] = x.rejected_steps;
+    }
     // leave copy 0 on the device equal to the host state
     e.intr[0].upload(e.h_intr.data(), e.h_intr.size(), e.stream);
     CBA_HIP(hipStreamSynchronize(e.stream));

@@ -348,6 +348,8 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     e.blk_acc.alloc(static_cast<size_t>(d.n_blocks) * e.NACC);
     if (d.chain != CBA_CHAIN_INTRINSIC) e.blk_mom.alloc(static_cast<size_t>(std::max(1, d.n_blocks)) * 256);
     if (const char* env = std::getenv("CBA_MODEB_MOMENTS")) e.modeb_moments = std::atoi(env);
+    if (const char* env = std::getenv("CBA_MODEB_SPLIT")) e.modeb_split = std::atoi(env);
+    if (const char* env = std::getenv("CBA_MODEB_SHARED")) e.modeb_shared = std::atoi(env);
     e.blk_s.alloc(d.n_blocks);
     e.scalar_out.alloc(8);
     e.cost_part.alloc(static_cast<size_t>(2 * ((d.n_blocks + 2047) / 2048 + 1)));  // allocated here: launch_cost may run inside a graph capture
@@ -554,6 +556,46 @@ cba_status cba_reproj_normal_eq_timed(cba_reproj* h, int32_t warmup, int32_t ite
     });
 }
 
+// tile-blocked layout out[tile][2 + 2P][128]: the residuals / Jacobian rows of residual blocks [b0, b1) into r / J, indexed
+// from the first observation of block b0 (walks the host copy of the tile table; one 34-KiB copy per tile)
+static void fetch_blocked_range(Engine& e, int b0, int b1, double* r, double* J) {
+    const int P = e.PL;
+    const int64_t tw = static_cast<int64_t>(2 + 2 * P) * TILE_A;
+    std::vector<double> buf(static_cast<size_t>(tw));
+    int64_t w = 0;
+    for (int b = 0; b < b0; ++b) w += (e.blk_offset[b + 1] - e.blk_offset[b] + TILE_A - 1) / TILE_A;
+    const int64_t base = e.blk_offset[b0];
+    for (int b = b0; b < b1; ++b) {
+        const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
+        for (int64_t s0 = 0; s0 < n; s0 += TILE_A, ++w) {
+            CBA_HIP(hipMemcpyAsync(buf.data(), e.J.p + w * tw, sizeof(double) * tw, hipMemcpyDeviceToHost, e.stream));
+            CBA_HIP(hipStreamSynchronize(e.stream));
+            const int64_t cnt = std::min<int64_t>(TILE_A, n - s0);
+            for (int64_t j = 0; j < cnt; ++j) {
+                const int64_t i = e.blk_offset[b] + s0 + j - base;
+                if (r) { r[2 * i] = buf[j]; r[2 * i + 1] = buf[TILE_A + j]; }
+                if (J)
+                    for (int k = 0; k < P; ++k) {
+                        J[(2 * i) * P + k] = buf[(2 + k) * TILE_A + j];
+                        J[(2 * i + 1) * P + k] = buf[(2 + P + k) * TILE_A + j];
+                    }
+            }
+        }
+    }
+}
+
+cba_status cba_reproj_eval_fetch_blocks(cba_reproj* h, int32_t b0, int32_t b1, double* r, double* J) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        CBA_HIP(hipSetDevice(e.device));
+        if (e.scalar) throw std::runtime_error("fp32 arithmetic selected: use cba_reproj_eval_fetch_f32");
+        if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
+        if (b0 < 0 || b1 < b0 || b1 > e.n_blocks) throw std::invalid_argument("block range outside the problem");
+        if (!e.eval_blocked_last) throw std::runtime_error("block-range fetch needs the tile-blocked output layout (the default)");
+        fetch_blocked_range(e, b0, b1, r, J);
+    });
+}
+
 cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
     return guarded([&] {
         Engine& e = *as_engine(h);
@@ -562,27 +604,7 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
         if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
         const int P = e.PL;
         if (e.eval_blocked_last) {
-            // tile-blocked layout out[tile][2 + 2P][128]: walk the tile table (host copy)
-            const int64_t tw = static_cast<int64_t>(2 + 2 * P) * TILE_A;
-            std::vector<double> buf(static_cast<size_t>(tw));
-            int64_t w = 0;
-            for (int b = 0; b < e.n_blocks; ++b) {
-                const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
-                for (int64_t s0 = 0; s0 < n; s0 += TILE_A, ++w) {
-                    CBA_HIP(hipMemcpyAsync(buf.data(), e.J.p + w * tw, sizeof(double) * tw, hipMemcpyDeviceToHost, e.stream));
-                    CBA_HIP(hipStreamSynchronize(e.stream));
-                    const int64_t cnt = std::min<int64_t>(TILE_A, n - s0);
-                    for (int64_t j = 0; j < cnt; ++j) {
-                        const int64_t i = e.blk_offset[b] + s0 + j;
-                        if (r) { r[2 * i] = buf[j]; r[2 * i + 1] = buf[TILE_A + j]; }
-                        if (J)
-                            for (int k = 0; k < P; ++k) {
-                                J[(2 * i) * P + k] = buf[(2 + k) * TILE_A + j];
-                                J[(2 * i + 1) * P + k] = buf[(2 + P + k) * TILE_A + j];
-                            }
-                    }
-                }
-            }
+            fetch_blocked_range(e, 0, e.n_blocks, r, J);
             return;
         }
         std::vector<double> hr(static_cast<size_t>(2 * e.ld));
@@ -689,6 +711,13 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
 
 cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode) {
     return guarded([&] { set_lm_mode(*as_engine(h), mode); });
+}
+
+cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats6[6]) {
+    return guarded([&] {
+        if (!h || !stats6) throw std::invalid_argument("null argument");
+        solve_stats(*reinterpret_cast<const Engine*>(h), stats6);
+    });
 }
 
 int64_t cba_reproj_covariance_dim(const cba_reproj* h) { return h ? covariance_dim(*reinterpret_cast<const Engine*>(h)) : 0; }

@@ -150,7 +150,8 @@ struct Tile {          // 32 bytes, read with scalar loads (wave-uniform)
 };
 
 constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
-constexpr int OPL_B = 16;    // Mode B/R: observations per lane per tile
+constexpr int OPL_B = 32;    // Mode B/R: observations per lane per tile (2048-observation tiles: the wave reduction and the
+                             // tile partial rows are paid once per tile)
 constexpr int TILE_B = 64 * OPL_B;
 
 struct Engine {
@@ -200,9 +201,14 @@ struct Engine {
     DevBuf<double> cost_part; // [2 * ceil(n_blocks / 2048)] partial cost pairs (only above 4096 blocks)
     DevBuf<double> blk_mom;   // [n_blocks][MomLayout::N] Mode B moment rows of the two-pose chains (kernels_reproj.hip)
     int modeb_moments = 1;    // 0 = accumulate the 12 pose columns directly (CBA_MODEB_MOMENTS=0, for A/B comparison)
+    int modeb_shared = 1;     // 1 = one workgroup per tile, the parts as its wavefronts, rows evaluated once and shared through LDS
+                              // (kernels_modeb.hip); 0 = one launch per part, every part re-evaluates the rows (CBA_MODEB_SHARED)
+    int modeb_split = -1;     // one-pose chain: 1 = pose rows | intrinsics block (mode_b.hpp SplitPoseIntr), 0 = round-robin halves,
+                              // -1 = per camera model as measured (CBA_MODEB_SPLIT)
 
     // ---- LM / Schur state (backend_hip.hip, resident_lm.hip; the rest lives in HipLMState, lm_state.hpp) ----------
     DevBuf<double> blk_w;       // [n_blocks] Huber weights rho'(s_b)
+    DevBuf<double> blk_acc_alt, blk_w_alt;  // the trial point's block sums / weights of a speculative LM step (backend_hip.hip sys_step)
     DevBuf<double> cam_acc;     // [n_cams][NACC] weighted per-camera sums
     DevBuf<double> view_L;      // [n_views][36] Cholesky factor of damped H_pp (lower, row-major)
     DevBuf<double> view_y;      // [n_views][6]
@@ -232,6 +238,7 @@ void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
 void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2
 void warm_reproj_kernels();                              // forces the code object of kernels_reproj.hip to load
 void launch_normal_eq(Engine& e);                       // Mode B: blk_acc[b] = [H | g | s]
+bool launch_normal_eq_shared_rows(Engine& e, double* rows);  // kernels_modeb.hip: the parts of a tile as one workgroup, rows through LDS
 void launch_cost(Engine& e, double huber_delta, double* out = nullptr);  // out (default scalar_out) = {1/2 sum rho(blk_s), sum blk_s}
 
 // backend_hip.hip
@@ -239,6 +246,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records = f
 void destroy_lm_state(Engine& e);
 void warm_lm(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
+void solve_stats(const Engine& e, int64_t stats6[6]);  // ExchangeStats of the last host-driven solve
 void set_lm_mode(Engine& e, int mode);  // 0 host-driven iteration, 1 automatic (default), 2 resident kernel whenever it can run the problem
 void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
 int64_t covariance_dim(const Engine& e);

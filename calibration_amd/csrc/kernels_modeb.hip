@@ -1,0 +1,177 @@
+// kernels_modeb.hip — Mode B (per-block normal equations) with the row evaluation SHARED between the parts.
+//
+// The packed accumulator vector of a residual block ([H | g | s], or the moment row of the two-pose chains) does not fit one
+// lane's registers, so it is split over NP parts.  In kernels_reproj.hip every part is its own launch and re-evaluates the
+// residual / Jacobian rows of every observation: from the ISA, 150 of the 263 vector instructions per observation and part
+// (130 of 223 in the moment form) are that re-evaluation (profiles/r02_modeb_isa_mix.txt).  Here ONE WORKGROUP of NP wavefronts
+// owns a tile; wavefront p accumulates part p for ALL observations of the tile but evaluates the rows of only every NP-th
+// 64-observation chunk; the rows (14 / 11 double2 per observation) reach the other wavefronts of the workgroup through LDS:
+//
+//     per group of NP chunks, wavefront p:   evaluate rows of chunk p -> LDS[p], accumulate them
+//                                            barrier
+//                                            for q != p: read rows of chunk q from LDS[q] (same lane), accumulate
+//                                            barrier
+//
+// A lane reads back exactly what the same lane of another wavefront wrote: no transposition, unit-stride 16-byte LDS accesses.
+// Vector work per observation: R + NP * A instead of NP * (R + A)  (R rows, A accumulate share): 376 instead of 526 instructions
+// for the one-pose chain, 409 instead of 669 for the moment form.  Results equal the per-part launches bit for bit: the same
+// products are added to the same accumulators in the same observation order (chunks in order, lanes fixed).
+#include "engine.hpp"
+#include "mode_b.hpp"
+#include "reproj_math.hpp"
+#include "wave_reduce.hpp"
+
+namespace cba {
+
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+// ---- the two accumulation forms behind one interface ------------------------------------------------------------------------
+template <int CHAIN, int MODEL, class SPLIT, typename T>
+struct DirectForm {
+    using D = DirectRows<CHAIN, MODEL>;
+    static constexpr int NROW = D::N, NPARTS = SPLIT::parts, NTOT = D::PL * (D::PL + 1) / 2 + D::PL + 1;
+    static constexpr int count(int part) { return SPLIT::count(D::PL, part); }
+    static __device__ __forceinline__ int entry(int part, int l) { return SPLIT::entry(D::PL, part, l); }
+    static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
+        direct_rows<CHAIN, MODEL, T>(bcp, ip, sp, x, y, u, v, w);
+    }
+    template <int PART>
+    static __device__ __forceinline__ void accumulate(const double* w, double, double, double* acc) {
+        direct_accumulate<CHAIN, MODEL, SPLIT, PART>(w, acc);
+    }
+};
+
+template <int MODEL, int NP, typename T>
+struct MomentForm {
+    static constexpr int PI = IntrSize<MODEL>::value;
+    static constexpr int NROW = MomRows<PI>::N, NPARTS = NP, NTOT = MomLayout<PI>::N;
+    static constexpr int count(int part) { return (NTOT - part + NP - 1) / NP; }
+    static __device__ __forceinline__ int entry(int part, int l) { return l * NP + part; }
+    static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
+        mom_rows<MODEL, T>(bcp, ip, sp, x, y, u, v, w);
+    }
+    template <int PART>
+    static __device__ __forceinline__ void accumulate(const double* w, double x, double y, double* acc) {
+        mom_accumulate<PI, NP, PART>(w, x, y, acc);
+    }
+};
+
+template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW + 1) / 2; };
+
+// the work of wavefront PART of the workgroup
+template <class FORM, int PART, typename T>
+__device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
+                                               const T* u, const T* v, v2f64 (*sh)[ShareDims<FORM>::NR2][64], double* out) {
+    constexpr int NP = FORM::NPARTS, NROW = FORM::NROW, NR2 = ShareDims<FORM>::NR2;
+    constexpr int NLOC = FORM::count(PART), NPAD = TransposeSum<16>::pad(NLOC);
+    double acc[NPAD];
+#pragma unroll
+    for (int e = 0; e < NPAD; ++e) acc[e] = 0.0;
+    const int n_groups = (t.count + 64 * NP - 1) / (64 * NP);  // the same for every wavefront of the workgroup
+    T xc = T(0), yc = T(0), uc = T(0), vc = T(0);
+    {
+        const int j = PART * 64 + lane;
+        if (j < t.count) { xc = X[t.xy_start + j]; yc = Y[t.xy_start + j]; uc = u[t.start + j]; vc = v[t.start + j]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see k_normal_eq
+#pragma unroll 1
+    for (int g = 0; g < n_groups; ++g) {
+        const int j = (g * NP + PART) * 64 + lane;
+        T xn = T(0), yn = T(0), un = T(0), vn = T(0);
+        if (j + 64 * NP < t.count) {  // the loads of the next group's own chunk, before this group's arithmetic
+            const int64_t i = t.start + j + 64 * NP, k2 = t.xy_start + j + 64 * NP;
+            xn = X[k2]; yn = Y[k2]; un = u[i]; vn = v[i];
+        }
+        if (j < t.count) {
+            double w[2 * NR2];
+            FORM::rows(bcp, ip, sp, xc, yc, uc, vc, w);
+            if (NROW & 1) w[NROW] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NR2; ++k) sh[PART][k][lane] = v2f64{w[2 * k], w[2 * k + 1]};
+            FORM::template accumulate<PART>(w, static_cast<double>(xc), static_cast<double>(yc), acc);
+        }
+        __syncthreads();  // every wavefront's rows of this group are in LDS
+#pragma unroll
+        for (int q = 1; q < NP; ++q) {
+            constexpr int dummy = 0; (void)dummy;
+            const int p = (PART + q) % NP;  // start with the neighbour: the NP wavefronts read NP different LDS regions at a time
+            const int jo = (g * NP + p) * 64 + lane;
+            if (jo < t.count) {
+                double w[2 * NR2];
+#pragma unroll
+                for (int k = 0; k < NR2; ++k) { const v2f64 d = sh[p][k][lane]; w[2 * k] = d.x; w[2 * k + 1] = d.y; }
+                const double xo = static_cast<double>(X[t.xy_start + jo]), yo = static_cast<double>(Y[t.xy_start + jo]);
+                FORM::template accumulate<PART>(w, xo, yo, acc);
+            }
+        }
+        __syncthreads();  // before the next group overwrites the rows
+        xc = xn; yc = yn; uc = un; vc = vn;
+    }
+    bool owner;
+    const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
+#pragma unroll
+    for (int jj = 0; jj < TransposeSum<NPAD>::CNT; ++jj) {
+        const int l = base + jj;
+        if (owner && l < NLOC) {
+            const int e = FORM::entry(PART, l);
+            if (e < FORM::NTOT) out[e] = acc[jj];
+        }
+    }
+}
+
+// one workgroup of FORM::NPARTS wavefronts per tile
+template <class FORM, typename T>
+__global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
+                                                                  const T* __restrict__ intr, const T* __restrict__ sd,
+                                                                  const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
+                                                                  const T* __restrict__ Y, const T* __restrict__ u, const T* __restrict__ v,
+                                                                  int PI, double* __restrict__ partial) {
+    __shared__ v2f64 sh[FORM::NPARTS][ShareDims<FORM>::NR2][64];
+    const int64_t w = blockIdx.x;
+    if (w >= n_tiles) return;
+    const Tile t = tiles[w];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const T* bcp = bc + static_cast<int64_t>(t.blk) * BC_SIZE;
+    const int cam = blk_cam[t.blk];
+    const T* ip = intr + static_cast<int64_t>(cam) * PI;
+    const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
+    double* out = partial + w * FORM::NTOT;
+    if (wave == 0) ne_shared_body<FORM, 0, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------------
+template <class FORM, typename T>
+static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
+    hipLaunchKernelGGL((k_ne_shared<FORM, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
+                       e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+}
+
+template <class F64, class F32>
+static void launch_both(Engine& e, double* rows) {
+    if (e.scalar) launch_form<F32, float>(e, e.bcf.p, e.intrf.p, e.sdf.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, rows);
+    else launch_form<F64, double>(e, e.bc.p, e.intr[e.active].p, e.sd.p, e.X.p, e.Y.p, e.u.p, e.v.p, rows);
+}
+
+// the shared-rows kernel of this engine's chain / model writing one row per tile into `rows` (row stride = the form's NTOT);
+// returns false when there is no such kernel (the caller then uses the per-part launches)
+bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
+    if (e.n_tilesB == 0) return true;
+    if (e.chain == CH_INTRINSIC) {
+        if (e.model == CAM_PINHOLE_BC)
+            launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>>(e, rows);
+        else
+            launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, float>>(e, rows);
+    } else {
+        if (!e.modeb_moments) return false;
+        if (e.model == CAM_PINHOLE_BC) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
+        else launch_both<MomentForm<CAM_SCHEIMPFLUG, 4, double>, MomentForm<CAM_SCHEIMPFLUG, 4, float>>(e, rows);
+    }
+    CBA_HIP(hipGetLastError());
+    return true;
+}
+
+}  // namespace cba

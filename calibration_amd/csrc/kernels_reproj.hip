@@ -265,8 +265,13 @@ __global__ void k_cost_final(int n_part, const double* __restrict__ part, double
 
 // ---- Mode B -----------------------------------------------------------------------------------
 // one tile per wavefront; the body (and the notes on the part split and the row masks) is mode_b.hpp
-template <int CHAIN, int MODEL, int NPARTS, int PART, typename T>
-__global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tiles, int64_t n_tiles,
+#ifndef CBA_NE_MINWAVES
+#define CBA_NE_MINWAVES 1  // waves per SIMD the Mode B kernels are compiled for (register budget 512 / CBA_NE_MINWAVES).  Measured
+                           // (profiles/r02_modeb_variants.jsonl): the pinhole kernels fit 2 waves either way; the Scheimpflug ones need ~270
+                           // registers, and one wave with 14-26 values in AGPRs (0.33 ms at C5) beats two waves spilling to scratch (0.49 ms)
+#endif
+template <int CHAIN, int MODEL, class SPLIT, int PART, typename T>
+__global__ __launch_bounds__(256, CBA_NE_MINWAVES) void k_normal_eq(const Tile* __restrict__ tiles, int64_t n_tiles,
                                                    const T* __restrict__ bc, const T* __restrict__ intr,
                                                    const T* __restrict__ sd, const int32_t* __restrict__ blk_cam,
                                                    const T* __restrict__ X, const T* __restrict__ Y,
@@ -280,8 +285,8 @@ __global__ __launch_bounds__(256) void k_normal_eq(const Tile* __restrict__ tile
     const Tile t = tiles[w];
     const int lane = threadIdx.x & 63;
     const int cam = blk_cam[t.blk];
-    normal_eq_tile<CHAIN, MODEL, NPARTS, PART, T>(t, lane, bc + static_cast<int64_t>(t.blk) * BC_SIZE, intr + static_cast<int64_t>(cam) * PI,
-                                                  sd + static_cast<int64_t>(cam) * SD_SIZE, X, Y, u, v, partial + w * NACC);
+    normal_eq_tile_split<CHAIN, MODEL, SPLIT, PART, T>(t, lane, bc + static_cast<int64_t>(t.blk) * BC_SIZE, intr + static_cast<int64_t>(cam) * PI,
+                                                       sd + static_cast<int64_t>(cam) * SD_SIZE, X, Y, u, v, partial + w * NACC);
 }
 
 // ---- Mode B, two-pose chains: moments --------------------------------------------------------------------------
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
     constexpr int PI = IntrSize<MODEL>::value;
     constexpr int NMOM = MomLayout<PI>::N;
     constexpr int NLOC = (NMOM + NPARTS - 1) / NPARTS;
-    constexpr int NPAD = (NLOC + 63) / 64 * 64;
+    constexpr int NPAD = TransposeSum<16>::pad(NLOC);
     const int64_t w = wave_index();
     if (w >= n_tiles) return;
     const Tile t = tiles[w];
@@ -327,12 +332,13 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
         if (j < t.count) mom_point<MODEL, NPARTS, PART, T>(bcp, ip, sp, xc, yc, uc, vc, acc);
         xc = xn; yc = yn; uc = un; vc = vn;
     }
-    const int base = wave_transpose_sum<NPAD>(acc, lane);
+    bool owner;
+    const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
     double* out = partial + w * NMOM;
 #pragma unroll
-    for (int j = 0; j < NPAD / 64; ++j) {
+    for (int j = 0; j < TransposeSum<NPAD>::CNT; ++j) {
         const int e = (base + j) * NPARTS + PART;
-        if (e < NMOM) out[e] = acc[j];
+        if (owner && e < NMOM) out[e] = acc[j];
     }
 }
 
@@ -499,26 +505,36 @@ void launch_cost(Engine& e, double huber_delta, double* out) {
     CBA_HIP(hipGetLastError());
 }
 
-template <int C, int M, int NP, int PART>
+template <int C, int M, class SPLIT, int PART>
 static void launch_ne_part(Engine& e, unsigned g) {
     double* rows = one_tile_per_block(e) ? e.blk_acc.p : e.partial.p;
     if (e.scalar)
-        hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART, float>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bcf.p,
+        hipLaunchKernelGGL((k_normal_eq<C, M, SPLIT, PART, float>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bcf.p,
                            e.intrf.p, e.sdf.p, e.d_blk_cam.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, rows);
     else
-        hipLaunchKernelGGL((k_normal_eq<C, M, NP, PART, double>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
+        hipLaunchKernelGGL((k_normal_eq<C, M, SPLIT, PART, double>), dim3(g), dim3(256), 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p,
                            intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, rows);
 }
 template <int C, int M>
 static void launch_ne(Engine& e, unsigned g) {
-    if constexpr (C == CH_INTRINSIC) {  // P = 16 / 18: 153 / 190 accumulators -> 2 parts
-        launch_ne_part<C, M, 2, 0>(e, g);
-        launch_ne_part<C, M, 2, 1>(e, g);
+    if (e.modeb_shared && launch_normal_eq_shared_rows(e, one_tile_per_block(e) ? e.blk_acc.p : e.partial.p)) return;  // kernels_modeb.hip
+    if constexpr (C == CH_INTRINSIC) {  // P = 16 / 18: 153 / 190 accumulators -> pose rows (87 / 99) | intrinsics block (66 / 91)
+        // measured (profiles/r02_modeb_variants.jsonl): pose rows | intrinsics block wins for Scheimpflug (C5 0.357 -> 0.329 ms: the
+        // intrinsics part drops the pose columns from its row evaluation) and loses for pinhole (C2 0.219 -> 0.222..0.237 ms: its
+        // 87-accumulator part needs 262 registers); CBA_MODEB_SPLIT=0|1 forces one form
+        const bool split = e.modeb_split < 0 ? M == CAM_SCHEIMPFLUG : e.modeb_split != 0;
+        if (split) {
+            launch_ne_part<C, M, SplitPoseIntr, 0>(e, g);
+            launch_ne_part<C, M, SplitPoseIntr, 1>(e, g);
+        } else {
+            launch_ne_part<C, M, SplitRoundRobin<2>, 0>(e, g);
+            launch_ne_part<C, M, SplitRoundRobin<2>, 1>(e, g);
+        }
     } else {  // P = 22 / 24: 276 / 325 accumulators -> 4 parts
-        launch_ne_part<C, M, 4, 0>(e, g);
-        launch_ne_part<C, M, 4, 1>(e, g);
-        launch_ne_part<C, M, 4, 2>(e, g);
-        launch_ne_part<C, M, 4, 3>(e, g);
+        launch_ne_part<C, M, SplitRoundRobin<4>, 0>(e, g);
+        launch_ne_part<C, M, SplitRoundRobin<4>, 1>(e, g);
+        launch_ne_part<C, M, SplitRoundRobin<4>, 2>(e, g);
+        launch_ne_part<C, M, SplitRoundRobin<4>, 3>(e, g);
     }
 }
 
@@ -544,7 +560,9 @@ template <int C, int M>
 static void launch_mom(Engine& e, unsigned g) {
     constexpr int PI = IntrSize<M>::value;
     constexpr int NMOM = MomLayout<PI>::N;
-    if constexpr (M == CAM_PINHOLE_BC) {  // 201 sums -> 3 parts of 67
+    if (e.modeb_shared && launch_normal_eq_shared_rows(e, one_tile_per_block(e) ? e.blk_mom.p : e.partial.p)) {
+        // one workgroup of 3 / 4 wavefronts per tile, rows evaluated once (kernels_modeb.hip)
+    } else if constexpr (M == CAM_PINHOLE_BC) {  // 201 sums -> 3 parts of 67
         launch_mom_part<M, 3, 0>(e, g); launch_mom_part<M, 3, 1>(e, g); launch_mom_part<M, 3, 2>(e, g);
     } else {                    // 244 sums -> 4 parts of 61
         launch_mom_part<M, 4, 0>(e, g); launch_mom_part<M, 4, 1>(e, g); launch_mom_part<M, 4, 2>(e, g); launch_mom_part<M, 4, 3>(e, g);

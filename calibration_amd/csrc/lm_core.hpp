@@ -10,6 +10,10 @@
 // DESIGN.md "Solver semantics" for the restated rules and the one known deviation (no Armijo
 // line search on bounds-constrained problems).
 //
+// Exchange pattern: every linear solve exchanges ONE packed buffer (PackLayout).  A trial point is
+// linearised speculatively (Backend::sys_step) so that the step statistics and the next system travel together: an accepted
+// step whose gain ratio is >= 0.937 (radius x 3, the usual case once the iteration converges) costs exactly one all-reduce.
+//
 // All O(#observations) and O(#views) arithmetic happens in the Backend (HIP kernels); this file
 // only handles the reduced system (<= a few hundred unknowns), the accept/reject control flow,
 // the shared parameter update and the one sum-all-reduce per linear solve.
@@ -18,6 +22,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -35,6 +40,26 @@ struct TrialStats {
     double gd = 0, dHd = 0;       // this rank's views' share of g^T d and d^T H d (private + cross terms)
     double step2 = 0, xnorm2 = 0; // private (per-view) share of |x+ - x|^2 and |x|^2
     double cost = 0;              // 1/2 sum_b rho(s_b) at the trial point, this rank's blocks
+};
+
+using AllReduce = std::function<void(double*, int64_t)>;
+
+// Layout of the ONE packed buffer a linear solve exchanges between ranks: everything is a sum over ranks;
+// the private-gradient max travels as one slot per rank (sum of a one-hot vector), so a single sum-all-reduce serves all.
+//   [ step statistics (5) | per-camera weighted sums (n_cams * NACC) | cost | #failed views | S_schur (n*n) | g_schur (n) | gmax slots ]
+struct PackLayout {
+    int64_t stats = 0, cam = 5, cost = 0, nfail = 0, S = 0, g = 0, gmax = 0, size = 0;
+    int n = 0, n_ranks = 1;
+    enum { GD = 0, DHD = 1, STEP2 = 2, XNORM2 = 3, TRIAL_COST = 4 };
+    PackLayout() = default;
+    PackLayout(const Structure& s, int ranks) : n(s.nsh), n_ranks(ranks) {
+        cost = cam + static_cast<int64_t>(s.n_cams) * s.NACC;
+        nfail = cost + 1;
+        S = nfail + 1;
+        g = S + static_cast<int64_t>(n) * n;
+        gmax = g + n;
+        size = gmax + n_ranks;
+    }
 };
 
 struct Backend {
@@ -59,16 +84,80 @@ struct Backend {
     virtual void accept() = 0;  // private copy 1 -> copy 0
     virtual void download_private(double* view_pose) = 0;
     virtual void download_blocks(std::vector<double>& acc, std::vector<double>& w) = 0;
+
+    // ---- packed systems: `pack` (PackLayout) leaves every call holding the sums OVER ALL RANKS after exactly ONE
+    // sum-all-reduce.  A backend with a device-side collective packs and reduces on the device (backend_hip.hip over RCCL);
+    // these defaults pack on the host and call `ar`.
+    // a new linearisation at copy 0 + elimination with `radius`: fills [cam .. gmax]
+    virtual void sys_new(double huber, double radius, bool init_scale, bool constrained, const PackLayout& L, const AllReduce& ar,
+                         int rank, double* pack) {
+        std::vector<double> cam_acc, S, g;
+        double cost2[2] = {0, 0}, gm = 0;
+        int nf = 0;
+        normal_eq_schur(huber, cam_acc, cost2, radius, init_scale, constrained, S, g, &gm, &nf);
+        std::fill(pack, pack + L.size, 0.0);
+        std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
+        pack[L.cost] = cost2[0];
+        pack[L.nfail] = nf;
+        std::copy(S.begin(), S.end(), pack + L.S);
+        std::copy(g.begin(), g.end(), pack + L.g);
+        pack[L.gmax + rank] = gm;
+        ar(pack + L.cam, L.size - L.cam);
+    }
+    // re-elimination of the current linearisation with another radius: fills [nfail .. g]
+    virtual void sys_resolve(double radius, bool constrained, const PackLayout& L, const AllReduce& ar, int rank, double* pack) {
+        std::vector<double> S, g;
+        double gm = 0;
+        int nf = 0;
+        schur(radius, false, constrained, S, g, &gm, &nf);
+        pack[L.nfail] = nf;
+        std::copy(S.begin(), S.end(), pack + L.S);
+        std::copy(g.begin(), g.end(), pack + L.g);
+        ar(pack + L.nfail, L.gmax - L.nfail);
+        (void)rank;
+    }
+    // The SPECULATIVE step: back-substitute delta_sh (trial poses, the views' model-cost terms), then linearise AT THE TRIAL
+    // POINT (copy 1, uploaded before) into the backend's second set of block sums, and eliminate with `radius_next` — the radius the
+    // step will have if it is accepted with a gain ratio >= 0.937 (Ceres grows the radius by its maximum factor 3 then).
+    // Fills the whole pack: the step statistics AND the next system travel in ONE all-reduce.  accept_step() makes the trial
+    // linearisation the current one; after a rejected step the current block sums are untouched (sys_resolve works on them).
+    // Returns false when the backend has no speculative path (the driver then uses trial() / sys_new()).
+    virtual bool sys_step(const double* delta_sh, double huber, double radius_next, bool constrained, const PackLayout& L,
+                          const AllReduce& ar, int rank, double* pack) {
+        (void)delta_sh; (void)huber; (void)radius_next; (void)constrained; (void)L; (void)ar; (void)rank; (void)pack;
+        return false;
+    }
+    virtual void accept_step() {}
+    // collectives the backend issued itself (device-side packing + RCCL): the driver adds them to its ExchangeStats
+    int64_t device_allreduce_calls = 0, device_allreduce_doubles = 0;
 };
 
-using AllReduce = std::function<void(double*, int64_t)>;
+// what a solve exchanged (cba_reproj_solve_stats)
+struct ExchangeStats {
+    int64_t allreduce_calls = 0, allreduce_doubles = 0;
+    int32_t speculative_steps = 0;   // trial points linearised ahead of the accept decision
+    int32_t speculation_hits = 0;    // ... accepted with the predicted radius: ONE collective for the whole LM step
+    int32_t speculation_misses = 0;  // ... accepted with another radius: one re-elimination + collective more
+    int32_t rejected_steps = 0;
+};
 
 class LMDriver {
   public:
     LMDriver(const Structure& s, Backend& be, std::vector<double>& intr, std::vector<double>& cam,
              std::vector<double>& view, std::vector<double>& target, AllReduce ar, int n_ranks, int rank)
-        : s_(s), be_(be), intr_(intr), cam_(cam), view_(view), target_(target), ar_(std::move(ar)), n_ranks_(n_ranks),
-          rank_(rank) {}
+        : s_(s), be_(be), intr_(intr), cam_(cam), view_(view), target_(target), n_ranks_(n_ranks), rank_(rank), L_(s, n_ranks) {
+        ar_ = [this, raw = std::move(ar)](double* buf, int64_t n) {  // every exchange of the solve goes through here or is
+            ++xs_.allreduce_calls;                                    // reported by the backend through note_exchange()
+            xs_.allreduce_doubles += n;
+            raw(buf, n);
+        };
+        pack_.assign(static_cast<size_t>(L_.size), 0.0);
+        if (const char* env = std::getenv("CBA_LM_SPECULATE")) speculate_ = std::atoi(env) != 0;
+    }
+    LMDriver(const LMDriver&) = delete;  // ar_ captures `this`
+    LMDriver& operator=(const LMDriver&) = delete;
+    void set_speculate(bool on) { speculate_ = on; }
+    const ExchangeStats& exchange_stats() const { return xs_; }
 
     // ---- masks: which blocks Ceres would hold constant ----------------------------------------
     void setup(const cba_options& o) {
@@ -127,12 +216,21 @@ class LMDriver {
         int iter = 0, invalid = 0, successful = 0;
 
         project_shared();  // Ceres projects the start point onto the bounds
+        xs_ = ExchangeStats();
         be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
         new_system(radius, true, huber);
         const double initial_cost = cost_;
         int term = CBA_TERM_FAILURE;
         const char* msg = "";
         std::vector<double> delta(n, 0.0), tintr, tcam, ttarget;
+        // After a rejected step the next trial is evaluated the cheap way (cost only): rejections come in runs, and a
+        // speculative linearisation that is thrown away costs a Mode B pass where Mode R would have done.
+        bool plain_next = false;
+        // ... and the trial point that will END the solve (|cost change| <= eps cost) is not worth linearising either: once the
+        // iteration converges the relative cost change of accepted steps falls geometrically (x 1/10 .. 1/100 per step), so it is
+        // extrapolated from the last two and the step predicted to fall below eps is evaluated the cheap way.  A wrong guess costs
+        // one extra exchange (plain trial, then the new system); a missed one costs a Mode B pass instead of a Mode R pass.
+        double rel_last = 0.0, rel_prev = 0.0;
 
         auto done = [&](int t, const char* m) { term = t; msg = m; };
         if (gmax_ <= eps) {
@@ -146,13 +244,25 @@ class LMDriver {
                 bool valid = solve_reduced(radius, delta);
                 TrialStats st;
                 double step2_sh = 0, xnorm2_sh = 0, model_change = 0;
+                bool speculated = false;
+                const double radius_spec = std::min(max_radius, 3.0 * radius);
                 if (valid) {
                     shared_plus(delta, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
                     be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
-                    be_.trial(delta.data(), huber, &st);
-                    double buf[5] = {st.gd, st.dHd, st.step2, st.xnorm2, st.cost};
-                    ar_(buf, 5);
-                    st.gd = buf[0]; st.dHd = buf[1]; st.step2 = buf[2]; st.xnorm2 = buf[3]; st.cost = buf[4];
+                    const bool expect_convergence = rel_prev > 0.0 && rel_last > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) <= eps;
+                    if (speculate_ && !plain_next && !expect_convergence)
+                        speculated = be_.sys_step(delta.data(), huber, radius_spec, constrained_, L_, ar_, rank_, pack_.data());
+                    if (speculated) {  // statistics and the next system arrived in the same exchange
+                        ++xs_.speculative_steps;
+                        st.gd = pack_[L_.stats + PackLayout::GD]; st.dHd = pack_[L_.stats + PackLayout::DHD];
+                        st.step2 = pack_[L_.stats + PackLayout::STEP2]; st.xnorm2 = pack_[L_.stats + PackLayout::XNORM2];
+                        st.cost = pack_[L_.stats + PackLayout::TRIAL_COST];
+                    } else {
+                        be_.trial(delta.data(), huber, &st);
+                        double buf[5] = {st.gd, st.dHd, st.step2, st.xnorm2, st.cost};
+                        ar_(buf, 5);
+                        st.gd = buf[0]; st.dHd = buf[1]; st.step2 = buf[2]; st.xnorm2 = buf[3]; st.cost = buf[4];
+                    }
                     // model_cost_change = -(J d)^T (r + J d / 2) = -g^T d - 1/2 d^T H d (trust_region_minimizer.cc);
                     // the views contributed their share, the shared-shared part is added here
                     double gd_sh = 0, dHd_sh = 0;
@@ -170,6 +280,7 @@ class LMDriver {
                     if (++invalid >= 5) { done(CBA_TERM_FAILURE, "Number of consecutive invalid steps more than max."); break; }
                     radius *= 0.5;
                     resolve(radius);
+                    plain_next = true;
                     continue;
                 }
                 invalid = 0;
@@ -182,25 +293,44 @@ class LMDriver {
                 if (std::fabs(cost_change) <= eps * cost_) { done(CBA_TERM_CONVERGENCE, "Function tolerance reached."); break; }
                 const double rel = cost_change / model_change;
                 if (o.verbose)
-                    std::printf("[cba] it %3d cost %.12e cand %.12e rel %.3e radius %.3e |g| %.3e\n", iter, cost_, cand_cost,
-                                rel, radius, gmax_);
+                    std::printf("[cba] it %3d cost %.12e cand %.12e rel %.3e radius %.3e |g| %.3e%s\n", iter, cost_, cand_cost,
+                                rel, radius, gmax_, speculated ? " (speculative)" : "");
                 if (rel > min_rel_decrease) {
                     intr_ = tintr; cam_ = tcam; target_ = ttarget;
-                    be_.accept();
-                    be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
                     ++successful;
+                    rel_prev = rel_last;
+                    rel_last = std::fabs(cost_change) / cost_;
                     radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
                     radius = std::min(max_radius, radius);
                     decrease_factor = 2.0;
-                    new_system(radius, false, huber);
+                    plain_next = false;
+                    if (speculated) {
+                        be_.accept_step();  // the trial linearisation (block sums, weights, poses) becomes the current one
+                        adopt_system(false);
+                        if (radius != radius_spec) {  // gain ratio below 0.937: the elimination was made with another radius
+                            ++xs_.speculation_misses;
+                            resolve(radius);
+                        } else {
+                            ++xs_.speculation_hits;
+                        }
+                    } else {
+                        be_.accept();
+                        be_.upload_shared(0, intr_.data(), cam_.data(), target_.data());
+                        new_system(radius, false, huber);
+                    }
                 } else {
+                    ++xs_.rejected_steps;
                     radius = radius / decrease_factor;
                     decrease_factor *= 2.0;
                     resolve(radius);
+                    plain_next = true;
                 }
             }
         }
         if (!view_.empty()) be_.download_private(view_.data());
+        xs_.allreduce_calls += be_.device_allreduce_calls;
+        xs_.allreduce_doubles += be_.device_allreduce_doubles;
+        be_.device_allreduce_calls = be_.device_allreduce_doubles = 0;
         out->termination = term;
         out->success = term == CBA_TERM_CONVERGENCE;
         out->iterations = iter;
@@ -442,27 +572,20 @@ class LMDriver {
 
     // Evaluate J at the current point and eliminate with `radius`: one packed all-reduce.
     void new_system(double radius, bool init_scale, double huber) {
+        be_.sys_new(huber, radius, init_scale, constrained_, L_, ar_, rank_, pack_.data());
+        adopt_system(init_scale);
+    }
+
+    // pack_ holds an all-reduced linearisation (from sys_new or an accepted sys_step): make it the current system
+    void adopt_system(bool init_scale) {
         const int n = s_.nsh;
-        std::vector<double> cam_acc, S, g;
-        double cost2[2] = {0, 0}, gmax_priv = 0;
-        int nfail = 0;
-        be_.normal_eq_schur(huber, cam_acc, cost2, radius, init_scale, constrained_, S, g, &gmax_priv, &nfail);
-        const size_t nca = cam_acc.size();
-        std::vector<double> buf(nca + 2 + static_cast<size_t>(n) * n + n + n_ranks_, 0.0);
-        std::memcpy(buf.data(), cam_acc.data(), sizeof(double) * nca);
-        buf[nca] = cost2[0];
-        buf[nca + 1] = nfail;
-        std::memcpy(&buf[nca + 2], S.data(), sizeof(double) * S.size());
-        std::memcpy(&buf[nca + 2 + static_cast<size_t>(n) * n], g.data(), sizeof(double) * n);
-        buf[nca + 2 + static_cast<size_t>(n) * n + n + rank_] = gmax_priv;  // max over ranks via per-rank slots
-        ar_(buf.data(), static_cast<int64_t>(buf.size()));
-        cam_acc.assign(buf.begin(), buf.begin() + nca);
-        cost_ = buf[nca];
-        nfail_ = static_cast<int>(buf[nca + 1] + 0.5);
-        Ssch_.assign(buf.begin() + nca + 2, buf.begin() + nca + 2 + static_cast<size_t>(n) * n);
-        gsch_.assign(buf.begin() + nca + 2 + static_cast<size_t>(n) * n, buf.begin() + nca + 2 + static_cast<size_t>(n) * n + n);
+        const std::vector<double> cam_acc(pack_.begin() + L_.cam, pack_.begin() + L_.cost);
+        cost_ = pack_[L_.cost];
+        nfail_ = static_cast<int>(pack_[L_.nfail] + 0.5);
+        Ssch_.assign(pack_.begin() + L_.S, pack_.begin() + L_.g);
+        gsch_.assign(pack_.begin() + L_.g, pack_.begin() + L_.gmax);
         double gm = 0;
-        for (int r = 0; r < n_ranks_; ++r) gm = std::max(gm, buf[nca + 2 + static_cast<size_t>(n) * n + n + r]);
+        for (int r = 0; r < n_ranks_; ++r) gm = std::max(gm, pack_[L_.gmax + r]);  // max over ranks via per-rank slots
         Hcc_.assign(static_cast<size_t>(n) * n, 0.0);
         gc_.assign(n, 0.0);
         assemble_shared(cam_acc, Hcc_, gc_);
@@ -480,19 +603,10 @@ class LMDriver {
     }
 
     void resolve(double radius) {
-        const int n = s_.nsh;
-        std::vector<double> S, g;
-        double gmax_priv = 0;
-        int nfail = 0;
-        be_.schur(radius, false, constrained_, S, g, &gmax_priv, &nfail);
-        std::vector<double> buf(1 + static_cast<size_t>(n) * n + n, 0.0);
-        buf[0] = nfail;
-        std::memcpy(&buf[1], S.data(), sizeof(double) * S.size());
-        std::memcpy(&buf[1 + static_cast<size_t>(n) * n], g.data(), sizeof(double) * n);
-        ar_(buf.data(), static_cast<int64_t>(buf.size()));
-        nfail_ = static_cast<int>(buf[0] + 0.5);
-        Ssch_.assign(buf.begin() + 1, buf.begin() + 1 + static_cast<size_t>(n) * n);
-        gsch_.assign(buf.begin() + 1 + static_cast<size_t>(n) * n, buf.end());
+        be_.sys_resolve(radius, constrained_, L_, ar_, rank_, pack_.data());
+        nfail_ = static_cast<int>(pack_[L_.nfail] + 0.5);
+        Ssch_.assign(pack_.begin() + L_.S, pack_.begin() + L_.g);
+        gsch_.assign(pack_.begin() + L_.g, pack_.begin() + L_.gmax);
     }
 
     double shared_gmax() const {
@@ -591,6 +705,10 @@ class LMDriver {
     std::vector<double>&intr_, &cam_, &view_, &target_;
     AllReduce ar_;
     int n_ranks_, rank_;
+    PackLayout L_;
+    std::vector<double> pack_;
+    bool speculate_ = true;
+    ExchangeStats xs_;
     std::vector<char> active_, eff_;
     std::vector<char> cam_var_;
     std::vector<int32_t> view_fixed_;

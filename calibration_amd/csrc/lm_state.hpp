@@ -20,6 +20,10 @@ struct HipLMState {
     //   pin    [syrk tiles (n_pairs*4096) | g_schur (nsh) | gmax, #failed views]      pin_ne [camera sums | cost, sum s]
     //   pin_tr [8..12): step2, xnorm2, g^T d, d^T H d;  [24..26): trial cost, sum s
     PinnedBuf<double> pin, pin_ne, pin_tr;
+    // the packed exchange buffer of a linear solve (lm_core.hpp PackLayout): assembled and all-reduced on the device
+    DevBuf<double> pack_dev, sys_tiles, stat_dev;
+    PinnedBuf<double> pin_packed;
+    int64_t xs[6] = {0, 0, 0, 0, 0, 0};  // ExchangeStats of the last solve (cba_reproj_solve_stats)
     // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
     // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
     // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches

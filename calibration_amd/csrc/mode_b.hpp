@@ -12,8 +12,8 @@ namespace cba {
 
 // Per tile: H = sum J^T J (upper triangle, row-major packed), g = sum J^T r, s = sum |r|^2, all
 // UNWEIGHTED (the per-block Huber weight is a scalar applied when blocks are assembled).
-// The packed accumulator vector [H | g | s] is split round-robin over NPARTS passes so that one
-// lane's share stays in registers; every part re-evaluates the (cheap) Jacobian rows.
+// The packed accumulator vector [H | g | s] is split over several launches ("parts", see the split policies below) so that
+// one lane's share stays in registers; every part re-evaluates the Jacobian rows it needs.
 // T = float: the Jacobian rows are evaluated in fp32 and widened once; every accumulator stays fp64.
 //
 // The u and v rows of an observation are accumulated as two chained FMAs per entry, and only where the
@@ -27,16 +27,46 @@ struct RowMask {
     static constexpr bool v(int c) { return !(c == OI + 0 || c == OI + 2 || c == OI + 4); }
 };
 
-// out[e] (e % NPARTS == PART, e < NACC) = this tile's sums; the other entries of the row are left alone
-template <int CHAIN, int MODEL, int NPARTS, int PART, typename T>
-__device__ __forceinline__ void normal_eq_tile(const Tile t, int lane, const T* bcp, const T* ip,
-                                               const T* sp, const T* X, const T* Y,
-                                               const T* u, const T* v, double* out) {
+// ---- how the packed accumulator vector [H | g | s] is split over the launches ("parts") ----------------------------------
+// A split policy maps a packed entry e to (part, index within the part) and back.
+//   SplitRoundRobin<NP>: e -> (e % NP, e / NP): equal shares, every part needs every Jacobian column.
+//   SplitPoseIntr (one-pose chain): part 0 = the six pose rows of H (pose-pose and pose-intrinsics) and the pose gradient,
+//     part 1 = the intrinsics-intrinsics block, the intrinsics gradient and |r|^2.  Part 1 never touches a pose column, so
+//     the compiler drops d(u,v)/dP and the twelve pose entries from its row evaluation (~half of the row cost); the packed
+//     order makes both inverses closed forms (H is stored row by row, so the pose rows are a prefix of it).
+template <int NP>
+struct SplitRoundRobin {
+    static constexpr int parts = NP;
+    static constexpr int count(int PL, int part) { return (PL * (PL + 1) / 2 + PL + 1 - part + NP - 1) / NP; }
+    static constexpr int part_of(int PL, int e) { return e % NP; }
+    static constexpr int local(int PL, int e) { return e / NP; }
+    static __device__ __forceinline__ int entry(int PL, int part, int l) { return l * NP + part; }
+};
+struct SplitPoseIntr {
+    static constexpr int parts = 2;
+    static constexpr int nh(int PL) { return PL * (PL + 1) / 2; }
+    static constexpr int e6(int PL) { return 6 * PL - 15; }  // packed entries of H rows 0..5
+    static constexpr int count(int PL, int part) { return part == 0 ? e6(PL) + 6 : nh(PL) - e6(PL) + (PL - 6) + 1; }
+    static constexpr int part_of(int PL, int e) { return e < e6(PL) ? 0 : e < nh(PL) ? 1 : e < nh(PL) + 6 ? 0 : 1; }
+    static constexpr int local(int PL, int e) {
+        return e < e6(PL) ? e : e < nh(PL) ? e - e6(PL) : e < nh(PL) + 6 ? e6(PL) + (e - nh(PL)) : (nh(PL) - e6(PL)) + (e - nh(PL) - 6);
+    }
+    static __device__ __forceinline__ int entry(int PL, int part, int l) {
+        if (part == 0) return l < e6(PL) ? l : nh(PL) + (l - e6(PL));
+        return l < nh(PL) - e6(PL) ? e6(PL) + l : nh(PL) + 6 + (l - (nh(PL) - e6(PL)));
+    }
+};
+
+// out[e] (e in this part, e < NACC) = this tile's sums; the other entries of the row are left alone
+template <int CHAIN, int MODEL, class SPLIT, int PART, typename T>
+__device__ __forceinline__ void normal_eq_tile_split(const Tile t, int lane, const T* bcp, const T* ip,
+                                                     const T* sp, const T* X, const T* Y,
+                                                     const T* u, const T* v, double* out) {
     constexpr int PL = LocalCols<CHAIN, MODEL>::value;
     constexpr int NH = PL * (PL + 1) / 2;
     constexpr int NACC = NH + PL + 1;
-    constexpr int NLOC = (NACC + NPARTS - 1) / NPARTS;  // this part's share: entries e with e % NPARTS == PART, at e / NPARTS
-    constexpr int NPAD = (NLOC + 63) / 64 * 64;
+    constexpr int NLOC = SPLIT::count(PL, PART);  // this part's share
+    constexpr int NPAD = TransposeSum<16>::pad(NLOC);
     using M = RowMask<CHAIN>;
 
     double acc[NPAD];
@@ -71,32 +101,115 @@ __device__ __forceinline__ void normal_eq_tile(const Tile t, int lane, const T* 
             for (int a = 0; a < PL; ++a) {
 #pragma unroll
                 for (int b = a; b < PL; ++b) {
-                    if ((e % NPARTS) == PART) {
-                        if (M::u(a) && M::u(b)) acc[e / NPARTS] = __builtin_fma(Ju[a], Ju[b], acc[e / NPARTS]);
-                        if (M::v(a) && M::v(b)) acc[e / NPARTS] = __builtin_fma(Jv[a], Jv[b], acc[e / NPARTS]);
+                    if (SPLIT::part_of(PL, e) == PART) {
+                        if (M::u(a) && M::u(b)) acc[SPLIT::local(PL, e)] = __builtin_fma(Ju[a], Ju[b], acc[SPLIT::local(PL, e)]);
+                        if (M::v(a) && M::v(b)) acc[SPLIT::local(PL, e)] = __builtin_fma(Jv[a], Jv[b], acc[SPLIT::local(PL, e)]);
                     }
                     ++e;
                 }
             }
 #pragma unroll
             for (int a = 0; a < PL; ++a) {
-                if (((NH + a) % NPARTS) == PART) {
-                    if (M::u(a)) acc[(NH + a) / NPARTS] = __builtin_fma(Ju[a], rr[0], acc[(NH + a) / NPARTS]);
-                    if (M::v(a)) acc[(NH + a) / NPARTS] = __builtin_fma(Jv[a], rr[1], acc[(NH + a) / NPARTS]);
+                if (SPLIT::part_of(PL, NH + a) == PART) {
+                    if (M::u(a)) acc[SPLIT::local(PL, NH + a)] = __builtin_fma(Ju[a], rr[0], acc[SPLIT::local(PL, NH + a)]);
+                    if (M::v(a)) acc[SPLIT::local(PL, NH + a)] = __builtin_fma(Jv[a], rr[1], acc[SPLIT::local(PL, NH + a)]);
                 }
             }
-            if (((NH + PL) % NPARTS) == PART)
-                acc[(NH + PL) / NPARTS] = __builtin_fma(rr[1], rr[1], __builtin_fma(rr[0], rr[0], acc[(NH + PL) / NPARTS]));
+            if (SPLIT::part_of(PL, NH + PL) == PART)
+                acc[SPLIT::local(PL, NH + PL)] = __builtin_fma(rr[1], rr[1], __builtin_fma(rr[0], rr[0], acc[SPLIT::local(PL, NH + PL)]));
         }
         xc = xn; yc = yn; uc = un; vc = vn;
     }
-    // wave totals: lane ends up owning NPAD/64 of this part's entries (wave_reduce.hpp)
-    const int base = wave_transpose_sum<NPAD>(acc, lane);
+    // wave totals: an owning lane ends up with TransposeSum<NPAD>::CNT of this part's entries (wave_reduce.hpp)
+    bool owner;
+    const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
 #pragma unroll
-    for (int j = 0; j < NPAD / 64; ++j) {
-        const int e = (base + j) * NPARTS + PART;
-        if (e < NACC) out[e] = acc[j];
+    for (int j = 0; j < TransposeSum<NPAD>::CNT; ++j) {
+        const int l = base + j;
+        if (owner && l < NLOC) {
+            const int e = SPLIT::entry(PL, PART, l);
+            if (e < NACC) out[e] = acc[j];
+        }
     }
+}
+
+// the round-robin split of the first version (still what the resident kernel and the direct two-pose form use)
+template <int CHAIN, int MODEL, int NPARTS, int PART, typename T>
+__device__ __forceinline__ void normal_eq_tile(const Tile t, int lane, const T* bcp, const T* ip,
+                                               const T* sp, const T* X, const T* Y,
+                                               const T* u, const T* v, double* out) {
+    normal_eq_tile_split<CHAIN, MODEL, SplitRoundRobin<NPARTS>, PART, T>(t, lane, bcp, ip, sp, X, Y, u, v, out);
+}
+
+// ---- rows / accumulate split of both forms: what kernels_modeb.hip hands from the wavefront that evaluated an observation to
+// the wavefronts that accumulate the other parts ------------------------------------------------------------------------------
+// Direct form rows: w = [ r_u, r_v | Ju pose columns | Jv pose columns | live intrinsics entries of the u row | of the v row ]
+// (structural constants of the intrinsics columns are not shipped: see MomRows in reproj_math.hpp).
+template <int CHAIN, int MODEL>
+struct DirectRows {
+    static constexpr int PI = IntrSize<MODEL>::value, OI = CHAIN == CH_INTRINSIC ? 6 : 12, PL = OI + PI;
+    static constexpr int N = 2 + 2 * OI + MomRows<PI>::NU + MomRows<PI>::NV;
+};
+
+template <int CHAIN, int MODEL, typename T>
+__device__ __forceinline__ void direct_rows(const T* bcp, const T* ip, const T* sp, T x, T y, T uo, T vo, double* w) {
+    using D = DirectRows<CHAIN, MODEL>;
+    using R = MomRows<D::PI>;
+    T rt[2], Jut[D::PL], Jvt[D::PL];
+    reproj_point<CHAIN, MODEL, T>(bcp, ip, sp, x, y, uo, vo, rt, Jut, Jvt);
+    w[0] = rt[0]; w[1] = rt[1];
+    int n = 2;
+#pragma unroll
+    for (int a = 0; a < D::OI; ++a) w[n++] = Jut[a];
+#pragma unroll
+    for (int a = 0; a < D::OI; ++a) w[n++] = Jvt[a];
+#pragma unroll
+    for (int j = 0; j < D::PI; ++j)
+        if (R::u_live(j)) w[n++] = Jut[D::OI + j];
+#pragma unroll
+    for (int j = 0; j < D::PI; ++j)
+        if (R::v_live(j)) w[n++] = Jvt[D::OI + j];
+}
+
+template <int CHAIN, int MODEL, class SPLIT, int PART>
+__device__ __forceinline__ void direct_accumulate(const double* w, double* acc) {
+    using D = DirectRows<CHAIN, MODEL>;
+    using R = MomRows<D::PI>;
+    using M = RowMask<CHAIN>;
+    constexpr int PL = D::PL, NH = PL * (PL + 1) / 2;
+    double rr[2] = {w[0], w[1]}, Ju[PL], Jv[PL];
+    {
+        int n = 2;
+#pragma unroll
+        for (int a = 0; a < D::OI; ++a) Ju[a] = w[n++];
+#pragma unroll
+        for (int a = 0; a < D::OI; ++a) Jv[a] = w[n++];
+#pragma unroll
+        for (int j = 0; j < D::PI; ++j) Ju[D::OI + j] = R::u_live(j) ? w[n++] : (j == 2 ? 1.0 : 0.0);
+#pragma unroll
+        for (int j = 0; j < D::PI; ++j) Jv[D::OI + j] = R::v_live(j) ? w[n++] : (j == 3 ? 1.0 : 0.0);
+    }
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < PL; ++a) {
+#pragma unroll
+        for (int b = a; b < PL; ++b) {
+            if (SPLIT::part_of(PL, e) == PART) {
+                if (M::u(a) && M::u(b)) acc[SPLIT::local(PL, e)] = __builtin_fma(Ju[a], Ju[b], acc[SPLIT::local(PL, e)]);
+                if (M::v(a) && M::v(b)) acc[SPLIT::local(PL, e)] = __builtin_fma(Jv[a], Jv[b], acc[SPLIT::local(PL, e)]);
+            }
+            ++e;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < PL; ++a) {
+        if (SPLIT::part_of(PL, NH + a) == PART) {
+            if (M::u(a)) acc[SPLIT::local(PL, NH + a)] = __builtin_fma(Ju[a], rr[0], acc[SPLIT::local(PL, NH + a)]);
+            if (M::v(a)) acc[SPLIT::local(PL, NH + a)] = __builtin_fma(Jv[a], rr[1], acc[SPLIT::local(PL, NH + a)]);
+        }
+    }
+    if (SPLIT::part_of(PL, NH + PL) == PART)
+        acc[SPLIT::local(PL, NH + PL)] = __builtin_fma(rr[1], rr[1], __builtin_fma(rr[0], rr[0], acc[SPLIT::local(PL, NH + PL)]));
 }
 
 // the tile's sum of squared residuals; the total lands in LANE 63
@@ -105,9 +218,10 @@ __device__ __forceinline__ double resid_tile(const Tile t, int lane, const T* bc
                                              const T* sp, const T* X, const T* Y,
                                              const T* u, const T* v) {
     double s = 0.0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < OPL_B; ++k) {
         const int j = lane + 64 * k;
+        if (64 * k >= t.count) break;  // wave-uniform
         if (j < t.count) {
             const int64_t i = t.start + j, k2 = t.xy_start + j;
             T rr[2];

@@ -378,19 +378,47 @@ CBA_HD double mom_expand_entry(const double* mom, const double G[3][36], int e) 
     return s;
 }
 
-// One observation's contribution to the entries e (e % NPARTS == PART, kept at acc[e / NPARTS]) of the moment row.
-// u row of the intrinsics block has no fy / cy entry, v row no fx / cx / skew entry (as in RowMask of Mode B).
-template <int MODEL, int NPARTS, int PART, typename T>
-CBA_HD void mom_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, double* acc) {
+// The per-observation quantities the moment sums are built from ("moment rows"), in the order
+//   w = [ r_u, r_v | du[3] | dv[3] | the intrinsics entries of the u row that are not structural constants | those of the v row ]
+// Of the intrinsics columns [fx fy cx cy skew ...] the u row has no fy / cy entry and d u / d cx = 1, the v row has no fx / cx /
+// skew entry and d v / d cy = 1 (both camera models): 2 * PI - 7 live entries.  A wavefront that evaluated an observation hands
+// exactly these MomRows<PI>::N numbers to the wavefronts that accumulate other parts of the moment row (kernels_modeb.hip).
+template <int PI>
+struct MomRows {
+    static constexpr int NU = PI - 3, NV = PI - 4, N = 8 + NU + NV;
+    static constexpr bool u_live(int c) { return !(c == 1 || c == 2 || c == 3); }
+    static constexpr bool v_live(int c) { return !(c == 0 || c == 2 || c == 3 || c == 4); }
+};
+
+template <int MODEL, typename T>
+CBA_HD void mom_rows(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, double* w) {
     constexpr int PI = IntrSize<MODEL>::value;
-    using L = MomLayout<PI>;
+    using R = MomRows<PI>;
     T rt[2], Pt[3], dut[3], dvt[3], Juit[PI], Jvit[PI];
     reproj_core<MODEL, T>(bc, intr, sd, X, Y, uo, vo, rt, Pt, dut, dvt, Juit, Jvit);
+    w[0] = rt[0]; w[1] = rt[1];
+    for (int k = 0; k < 3; ++k) { w[2 + k] = dut[k]; w[5 + k] = dvt[k]; }
+    int n = 8;
+    for (int j = 0; j < PI; ++j)
+        if (R::u_live(j)) w[n++] = Juit[j];
+    for (int j = 0; j < PI; ++j)
+        if (R::v_live(j)) w[n++] = Jvit[j];
+}
+
+// One observation's contribution to the entries e (e % NPARTS == PART, kept at acc[e / NPARTS]) of the moment row, from its
+// moment rows w and its target point (x, y).
+template <int PI, int NPARTS, int PART>
+CBA_HD void mom_accumulate(const double* w, double x, double y, double* acc) {
+    using L = MomLayout<PI>;
+    using R = MomRows<PI>;
+    const double ru = w[0], rv = w[1];
     double du[3], dv[3], Jui[PI], Jvi[PI];
-    const double ru = rt[0], rv = rt[1];
-    for (int k = 0; k < 3; ++k) { du[k] = dut[k]; dv[k] = dvt[k]; }
-    for (int j = 0; j < PI; ++j) { Jui[j] = Juit[j]; Jvi[j] = Jvit[j]; }
-    const double x = X, y = Y;
+    for (int k = 0; k < 3; ++k) { du[k] = w[2 + k]; dv[k] = w[5 + k]; }
+    {
+        int n = 8;
+        for (int j = 0; j < PI; ++j) Jui[j] = R::u_live(j) ? w[n++] : (j == 2 ? 1.0 : 0.0);
+        for (int j = 0; j < PI; ++j) Jvi[j] = R::v_live(j) ? w[n++] : (j == 3 ? 1.0 : 0.0);
+    }
     const double m[3] = {1.0, x, y};
     const double mm[6] = {1.0, x, y, x * x, x * y, y * y};
 #define CBA_ACC(E, VALUE) if (((E) % NPARTS) == PART) acc[(E) / NPARTS] += (VALUE)
@@ -437,6 +465,15 @@ CBA_HD void mom_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T
     }
 #undef CBA_ACC
 #undef CBA_FMA
+}
+
+// both in one go (the one-wavefront-per-tile kernels and the CPU test build)
+template <int MODEL, int NPARTS, int PART, typename T>
+CBA_HD void mom_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, double* acc) {
+    constexpr int PI = IntrSize<MODEL>::value;
+    double w[MomRows<PI>::N];
+    mom_rows<MODEL, T>(bc, intr, sd, X, Y, uo, vo, w);
+    mom_accumulate<PI, NPARTS, PART>(w, static_cast<double>(X), static_cast<double>(Y), acc);
 }
 
 // ---- Huber (ceres::HuberLoss + Corrector with rho'' <= 0): weight = rho'(s), rho(s) ------------

@@ -356,6 +356,14 @@ class ReprojHandle:
         capi.check(self.lib, self.lib.cba_reproj_eval_fetch(self.h, dptr(r), dptr(J)))
         return r, J
 
+    def eval_fetch_blocks(self, b0: int, b1: int):
+        """Residuals and Jacobian rows of the residual blocks [b0, b1) only (cba_reproj_eval_fetch_blocks)."""
+        n, p = int(self.flat.blk_offset[b1] - self.flat.blk_offset[b0]), self.local_columns
+        r = np.zeros(2 * n)
+        J = np.zeros((2 * n, p))
+        capi.check(self.lib, self.lib.cba_reproj_eval_fetch_blocks(self.h, int(b0), int(b1), dptr(r), dptr(J)))
+        return r, J
+
     def set_scalar(self, scalar: int):
         """0 = fp64 per-observation arithmetic (default), 1 = fp32 (accumulators stay fp64)."""
         capi.check(self.lib, self.lib.cba_reproj_set_scalar(self.h, int(scalar)))
@@ -394,6 +402,13 @@ class ReprojHandle:
         """0 = host-driven LM iteration, 1 = automatic (default), 2 = the resident single-launch kernel whenever it can
         take the problem (cba_reproj_set_lm_mode)."""
         capi.check(self.lib, self.lib.cba_reproj_set_lm_mode(self.h, int(mode)))
+
+    def solve_stats(self) -> dict:
+        """What the last host-driven solve exchanged between ranks (cba_reproj_solve_stats)."""
+        a = (C.c_int64 * 6)()
+        capi.check(self.lib, self.lib.cba_reproj_solve_stats(self.h, a))
+        return dict(zip(("allreduce_calls", "allreduce_doubles", "speculative_steps", "speculation_hits", "speculation_misses",
+                         "rejected_steps"), (int(v) for v in a)))
 
     def solve(self, opts: CbaOptions) -> CbaSummary:
         s = CbaSummary()

@@ -91,14 +91,17 @@ def make_sequence(n_frames: int, rng) -> List[np.ndarray]:
     return out
 
 
-def random_view_poses(n_views: int, rng, dist=2.0, max_tilt_deg=25.0, jitter=0.10) -> List[np.ndarray]:
+def random_view_poses(n_views: int, rng, dist=2.0, max_tilt_deg=25.0, jitter=0.10, depth_spread=0.0) -> List[np.ndarray]:
     """Independent c_T_t poses: target ~`dist` m in front, tilted <= max_tilt (bench-scale scenes,
-    where a cumulative random walk of 1000+ motions would leave the field of view)."""
+    where a cumulative random walk of 1000+ motions would leave the field of view); depth_spread > 0
+    scales the distance of every view by U(1 - spread, 1 + spread)."""
     out = []
     for _ in range(n_views):
         ang = np.deg2rad(rng.uniform(5.0, max_tilt_deg))
         ax = rand_unit_axis(rng)
-        t = np.array([rng.uniform(-jitter, jitter), rng.uniform(-jitter, jitter), dist + rng.uniform(-jitter, jitter)])
+        tx, ty = rng.uniform(-jitter, jitter), rng.uniform(-jitter, jitter)  # (draw order x, y, z: the scenes of round 1 stay as they were)
+        z = dist + rng.uniform(-jitter, jitter) if depth_spread <= 0.0 else dist * rng.uniform(1.0 - depth_spread, 1.0 + depth_spread)
+        t = np.array([tx, ty, z])
         out.append(make_pose(t, ax, ang))
     return out
 
@@ -146,12 +149,16 @@ class Scene:
 
 
 def scene_intrinsics(n_views=20, rows=8, cols=11, spacing=0.02, model=capi.CAMERA_PINHOLE_BC, seed=7, noise_px=0.0,
-                     distortion=True, init="perturbed", first_view_global=0) -> Scene:
-    """C1 / C2 / C5-shaped problem: one camera, n_views views of a rows x cols grid."""
+                     distortion=True, init="perturbed", first_view_global=0, tau=None, max_tilt_deg=25.0, jitter=0.10,
+                     depth_spread=0.0) -> Scene:
+    """C1 / C2 / C5-shaped problem: one camera, n_views views of a rows x cols grid.  tau / max_tilt_deg / jitter /
+    depth_spread shape the conditioning (scene_intrinsics_wide)."""
     rng = np.random.default_rng(seed)
     cam = camera_gt(model, distortion)
+    if tau is not None and model == capi.CAMERA_SCHEIMPFLUG:
+        cam[10:12] = tau
     grid = make_target_grid(rows, cols, spacing)
-    poses = random_view_poses(n_views, rng)
+    poses = random_view_poses(n_views, rng, max_tilt_deg=max_tilt_deg, jitter=jitter, depth_spread=depth_spread)
     views = [render_view(cam, T, grid, noise_px, rng) for T in poses]
     if init == "gt":
         cam0, poses0 = cam.copy(), poses
@@ -164,6 +171,17 @@ def scene_intrinsics(n_views=20, rows=8, cols=11, spacing=0.02, model=capi.CAMER
                        first_view_global=first_view_global)
     return Scene(flat, cam.reshape(1, -1), gt_view_pose=np.stack([pose_from_matrix(T) for T in poses]),
                  meta=dict(kind="intrinsics", n_views=n_views, rows=rows, cols=cols, seed=seed, noise_px=noise_px))
+
+
+def scene_intrinsics_wide(n_views=20, model=capi.CAMERA_SCHEIMPFLUG, seed=3, noise_px=0.2, **kw) -> Scene:
+    """A WELL-CONDITIONED intrinsics scene: a 1.3 m x 0.9 m board, tilts up to 45 degrees, distances spread over 0.6 .. 1.4 of the
+    nominal 2 m, views shifted by up to 0.3 m, sensor tilt (0.2, -0.15) rad.  The default scenes follow the reference's test
+    geometry (a small board, mild tilts, one distance), which leaves the Scheimpflug tilt / principal point / focal length valley
+    nearly flat (condition number 1e8 .. 1e9 of the Jacobi-scaled Hessian); here the data determine every parameter and two
+    correct solvers agree to rounding."""
+    args = dict(rows=10, cols=14, spacing=0.1, tau=(0.2, -0.15), max_tilt_deg=45.0, jitter=0.3, depth_spread=0.4)
+    args.update(kw)
+    return scene_intrinsics(n_views, model=model, seed=seed, noise_px=noise_px, **args)
 
 
 def ring_cameras(n_cams: int, baseline=0.25, focus=2.0) -> List[np.ndarray]:
@@ -208,6 +226,41 @@ def scene_extrinsics(n_views=8, n_cams=2, rows=8, cols=11, spacing=0.02, model=c
     return Scene(flat, np.stack(cams), gt_cam_pose=np.stack([pose_from_matrix(T) for T in c_T_r]),
                  gt_view_pose=np.stack([pose_from_matrix(T) for T in r_T_t]),
                  meta=dict(kind="extrinsics", n_views=n_views, n_cams=n_cams, seed=seed))
+
+
+def scene_extrinsics_shard(n_views_total, v0, v1, n_cams=8, rows=50, cols=100, spacing=0.008, model=capi.CAMERA_PINHOLE_BC, seed=137,
+                           noise_px=0.2) -> Scene:
+    """The views [v0, v1) of a C3-shaped problem of n_views_total views, generated WITHOUT the other views (strong-scaling
+    bench: every rank builds only its shard, 5 GB for the whole of BASELINE configs[2]).  Everything shared (cameras, rig,
+    their initial values) depends on `seed` only; view v draws its pose, noise and initial perturbation from the stream
+    (seed, v), so the union over any partition is the same problem.  Global view 0 keeps its ground-truth pose (gauge:
+    extrinsics.cpp:123-126)."""
+    rng = np.random.default_rng(seed)
+    cams = []
+    for _ in range(n_cams):
+        cam = camera_gt(model, True)
+        cam[0:2] *= 1 + 0.01 * rng.uniform(-1, 1, 2)
+        cams.append(cam)
+    grid = make_target_grid(rows, cols, spacing)
+    c_T_r = ring_cameras(n_cams)
+    cams0 = [camera_init(c) for c in cams]
+    cr0 = [c_T_r[0]] + [perturb_pose(T, rng, 1.0, 0.01) for T in c_T_r[1:]]
+    blocks, bcam, bview, r_T_t, rt0 = [], [], [], [], []
+    for v in range(v0, v1):
+        vr = np.random.default_rng([seed, v])
+        T = random_view_poses(1, vr, max_tilt_deg=20.0)[0]
+        r_T_t.append(T)
+        for c in range(n_cams):
+            blocks.append(render_view(cams[c], c_T_r[c] @ T, grid, noise_px, vr))
+            bcam.append(c)
+            bview.append(v - v0)
+        rt0.append(T if v == 0 else perturb_pose(T, vr, 1.0, 0.01))
+    flat = FlatProblem(capi.CHAIN_EXTRINSIC, model, blocks, bcam, bview, np.stack(cams0),
+                       np.stack([pose_from_matrix(T) for T in cr0]), np.stack([pose_from_matrix(T) for T in rt0]), None,
+                       first_view_global=v0)
+    return Scene(flat, np.stack(cams), gt_cam_pose=np.stack([pose_from_matrix(T) for T in c_T_r]),
+                 gt_view_pose=np.stack([pose_from_matrix(T) for T in r_T_t]),
+                 meta=dict(kind="extrinsics", n_views=v1 - v0, n_views_total=n_views_total, n_cams=n_cams, seed=seed))
 
 
 def scene_bundle(n_poses=25, n_cams=1, rows=8, cols=11, spacing=0.02, model=capi.CAMERA_PINHOLE_BC, seed=2024,

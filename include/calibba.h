@@ -192,6 +192,9 @@ int64_t cba_reproj_num_observations(const cba_reproj* h);
  * the tangent space of ceres::QuaternionManifold (ambient 2Nx4 Jacobian times PlusJacobian). */
 cba_status cba_reproj_eval(cba_reproj* h);
 cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J);
+/* The same for the residual blocks [b0, b1) only: r [2 * n], J [2 * n][P] with n = observations of those blocks, indexed from
+ * the first observation of block b0.  For problems whose full Mode A output (59 GB at BASELINE config 3) must not cross PCIe. */
+cba_status cba_reproj_eval_fetch_blocks(cba_reproj* h, int32_t b0, int32_t b1, double* r, double* J);
 /* Runs `iters` back-to-back evaluations on the handle's stream bracketed by HIP events;
  * returns the average milliseconds per evaluation of the dominant kernel region. */
 cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, double* ms_per_eval);
@@ -228,6 +231,14 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
  * bundle <= 768 observations).
  * Both forms follow the same rules and agree to rounding. */
 cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
+
+/* What the last host-driven cba_reproj_solve on this handle exchanged between ranks (one packed
+ * sum-all-reduce per linear solve).  A trial point is linearised ahead of the accept decision, so an accepted step whose
+ * gain ratio is >= 0.937 (Ceres then grows the radius by its maximum factor 3, which is the radius the elimination was
+ * made with) costs exactly ONE collective; stats6 = {all-reduce calls, all-reduced doubles, speculative steps,
+ * of those accepted with the predicted radius, accepted with another radius (+1 re-elimination and collective),
+ * rejected steps}.  All zero after a resident-kernel solve.  CBA_LM_SPECULATE=0 selects the two-exchange sequence. */
+cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats6[6]);
 
 /* Covariance in the reference's layout (ceresutils.h:69-126): dense symmetric, AMBIENT block
  * sizes, block order = get_param_blocks() of the stage (intrinsics.cpp:34-50,

@@ -114,15 +114,16 @@ struct CpuBackend final : Backend {
         }
         return ss;
     }
-    void normal_eq(double hub, std::vector<double>& cam_acc, double cost2[2]) override {
-        consts(0);
+    void normal_eq(double hub, std::vector<double>& cam_acc, double cost2[2]) override { normal_eq_at(0, hub, cam_acc, cost2); }
+    void normal_eq_at(int w, double hub, std::vector<double>& cam_acc, double cost2[2]) {
+        consts(w);
         switch (s.chain * 2 + s.model) {
-            case 0: mode_b<CH_INTRINSIC, CAM_PINHOLE_BC>(0); break;
-            case 1: mode_b<CH_INTRINSIC, CAM_SCHEIMPFLUG>(0); break;
-            case 2: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); else mode_b<CH_EXTRINSIC, CAM_PINHOLE_BC>(0); break;
-            case 3: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); else mode_b<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(0); break;
-            case 4: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_PINHOLE_BC>(0); else mode_b<CH_BUNDLE, CAM_PINHOLE_BC>(0); break;
-            default: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); else mode_b<CH_BUNDLE, CAM_SCHEIMPFLUG>(0); break;
+            case 0: mode_b<CH_INTRINSIC, CAM_PINHOLE_BC>(w); break;
+            case 1: mode_b<CH_INTRINSIC, CAM_SCHEIMPFLUG>(w); break;
+            case 2: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_PINHOLE_BC>(w); else mode_b<CH_EXTRINSIC, CAM_PINHOLE_BC>(w); break;
+            case 3: if (use_moments) mode_b_moments<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(w); else mode_b<CH_EXTRINSIC, CAM_SCHEIMPFLUG>(w); break;
+            case 4: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_PINHOLE_BC>(w); else mode_b<CH_BUNDLE, CAM_PINHOLE_BC>(w); break;
+            default: if (use_moments) mode_b_moments<CH_BUNDLE, CAM_SCHEIMPFLUG>(w); else mode_b<CH_BUNDLE, CAM_SCHEIMPFLUG>(w); break;
         }
         cost2[0] = cost2[1] = 0;
         cam_acc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0);
@@ -142,6 +143,10 @@ struct CpuBackend final : Backend {
     }
     void schur(double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g, double* gmax_priv,
                int* nfail) override {
+        schur_at(0, radius, init_scale, constrained, S, g, gmax_priv, nfail);
+    }
+    void schur_at(int w, double radius, bool init_scale, bool constrained, std::vector<double>& S, std::vector<double>& g,
+                  double* gmax_priv, int* nfail) {
         const int n = s.nsh;
         S.assign(static_cast<size_t>(n) * n, 0.0);
         g.assign(n, 0.0);
@@ -152,7 +157,7 @@ struct CpuBackend final : Backend {
             const int32_t* blks = s.link_blk.data() + s.link_off[v];
             double gm = 0;
             const bool ok = schur_view_body(dims, nb, blks, blk_acc.data(), blk_w.data(), fixed[v] != 0, radius, init_scale, constrained,
-                                            &view[0][7 * static_cast<size_t>(v)], &vscale2[6 * static_cast<size_t>(v)], &vL[36 * static_cast<size_t>(v)],
+                                            &view[w][7 * static_cast<size_t>(v)], &vscale2[6 * static_cast<size_t>(v)], &vL[36 * static_cast<size_t>(v)],
                                             &vy[6 * static_cast<size_t>(v)], &vD[6 * static_cast<size_t>(v)], &vgp[6 * static_cast<size_t>(v)], blk_Z.data(), &gm);
             if (!ok) { ++*nfail; continue; }
             *gmax_priv = std::max(*gmax_priv, gm);
@@ -201,6 +206,43 @@ struct CpuBackend final : Backend {
         }
     }
     void accept() override { view[0] = view[1]; }
+    // the speculative step (lm_core.hpp Backend::sys_step): statistics from the current factors, then the linearisation and
+    // the elimination at the trial point; the current block sums and weights are kept until accept_step()
+    std::vector<double> alt_acc, alt_w;
+    bool sys_step(const double* delta_sh, double hub, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
+                  int rank, double* pack) override {
+        std::fill(pack, pack + L.size, 0.0);
+        for (int v = 0; v < s.n_views; ++v) {
+            const int nb = static_cast<int>(s.link_off[v + 1] - s.link_off[v]);
+            double o4[4];
+            backsub_view_body(dims, nb, s.link_blk.data() + s.link_off[v], s.blk_cam.data(), blk_Z.data(), delta_sh, fixed[v] != 0,
+                              &vL[36 * static_cast<size_t>(v)], &vy[6 * static_cast<size_t>(v)], &vD[6 * static_cast<size_t>(v)],
+                              &vgp[6 * static_cast<size_t>(v)], &view[0][7 * static_cast<size_t>(v)], &vdelta[6 * static_cast<size_t>(v)],
+                              &view[1][7 * static_cast<size_t>(v)], o4);
+            pack[L.stats + PackLayout::STEP2] += o4[0];
+            pack[L.stats + PackLayout::XNORM2] += o4[1];
+            pack[L.stats + PackLayout::GD] += o4[2];
+            pack[L.stats + PackLayout::DHD] += o4[3];
+        }
+        const std::vector<double> keep_acc = blk_acc, keep_w = blk_w;
+        std::vector<double> cam_acc, S, g;
+        double cost2[2], gm = 0;
+        int nf = 0;
+        normal_eq_at(1, hub, cam_acc, cost2);
+        schur_at(1, radius_next, false, constrained, S, g, &gm, &nf);
+        alt_acc = blk_acc; alt_w = blk_w;
+        blk_acc = keep_acc; blk_w = keep_w;
+        pack[L.stats + PackLayout::TRIAL_COST] = cost2[0];
+        std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
+        pack[L.cost] = cost2[0];
+        pack[L.nfail] = nf;
+        std::copy(S.begin(), S.end(), pack + L.S);
+        std::copy(g.begin(), g.end(), pack + L.g);
+        pack[L.gmax + rank] = gm;
+        ar(pack, L.size);
+        return true;
+    }
+    void accept_step() override { blk_acc = alt_acc; blk_w = alt_w; view[0] = view[1]; }
     void download_private(double* vp) override { std::memcpy(vp, view[0].data(), sizeof(double) * view[0].size()); }
     void download_blocks(std::vector<double>& acc, std::vector<double>& w) override { acc = blk_acc; w = blk_w; }
 };
@@ -243,8 +285,10 @@ extern "C" {
 const char* hm_last_error(void) { return g_err.c_str(); }
 
 // LM solve with the product's host driver + the CPU test backend.  allreduce may be NULL.
-int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
-                    cba_summary* out) {
+// speculate: 1 / 0 = linearise trial points ahead of the accept decision or not, -1 = the driver's default (CBA_LM_SPECULATE)
+// stats6 (may be NULL) = {all-reduce calls, all-reduced doubles, speculative steps, hits, misses, rejected steps}
+int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
+                       int speculate, cba_summary* out, int64_t* stats6) {
     return guarded([&] {
         Session ss;
         load(*d, ss);
@@ -253,9 +297,19 @@ int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allre
             if (fn && fn(buf, n, user) != 0) throw std::runtime_error("allreduce callback failed");
         };
         LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, ar, n_ranks, rank);
+        if (speculate >= 0) drv.set_speculate(speculate != 0);
         drv.solve(*o, out);
         store(*d, ss);
+        if (stats6) {
+            const ExchangeStats& x = drv.exchange_stats();
+            stats6[0] = x.allreduce_calls; stats6[1] = x.allreduce_doubles; stats6[2] = x.speculative_steps;
+            stats6[3] = x.speculation_hits; stats6[4] = x.speculation_misses; stats6[5] = x.rejected_steps;
+        }
     });
+}
+int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
+                    cba_summary* out) {
+    return hm_reproj_solve_ex(d, o, fn, user, n_ranks, rank, -1, out, nullptr);
 }
 
 // per-block packed [H | g | s] rows at the problem's parameters, through the direct (moments = 0) or the moment form

@@ -62,6 +62,7 @@ def load_hostmath():
     h.hm_last_error.restype = C.c_char_p
     h.hm_reproj_eval.argtypes = [PP, c_double_p, c_double_p]
     h.hm_reproj_solve.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, PS]
+    h.hm_reproj_solve_ex.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_int, PS, C.POINTER(C.c_int64)]
     h.hm_reproj_block_normal_eq.argtypes = [PP, C.c_int, c_double_p]
     h.hm_structure_check.argtypes = [PP, C.c_int]
     h.hm_reproj_masks.argtypes = [PP, PO, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
@@ -399,3 +400,54 @@ def semidlt_solve(fn, d, nr, o, lo=None, hi=None, fixed=None, want_cov=True):
             None if fi is None else fi.ctypes.data_as(c_int32_p), capi.dptr(fv), 0 if not fixed else len(fixed), C.byref(o), C.byref(s),
             capi.dptr(dist), capi.dptr(ve), capi.dptr(cov if want_cov else None))
     return st, k, p, s, dist, ve, cov
+
+
+# ---- conditioning analysis of an intrinsics problem (one-pose chain) -------------------------------------------------------------
+def _quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def tangent_delta(fa, fb) -> np.ndarray:
+    """delta with x_b = Plus(x_a, delta) for an INTRINSIC-chain problem, ordered [intrinsics | view 0 (rot 3, trans 3) | view 1 ...]:
+    intrinsics Euclidean; poses q_b = q(delta) * q_a (ceres::QuaternionManifold: left-multiplied, |delta| = half the angle) and
+    t_b = t_a + dt."""
+    d = [(fb.intr - fa.intr).reshape(-1)]
+    for pa, pb in zip(fa.view_pose.reshape(-1, 7), fb.view_pose.reshape(-1, 7)):
+        qa, qb = pa[:4] / np.linalg.norm(pa[:4]), pb[:4] / np.linalg.norm(pb[:4])
+        qd = _quat_mul(qb, qa * np.array([1.0, -1.0, -1.0, -1.0]))
+        n = np.linalg.norm(qd[1:])
+        v = qd[1:] / n * np.arctan2(n, qd[0]) if n > 0 else np.zeros(3)
+        d.append(np.concatenate([v, pb[4:] - pa[4:]]))
+    return np.concatenate(d)
+
+
+def intrinsic_chain_hessian(orc, flat) -> np.ndarray:
+    """J^T J of an INTRINSIC-chain problem in the tangent space, same ordering as tangent_delta, from the oracle's Jacobian."""
+    _r, J = oracle_eval(orc, flat)  # rows [pose (6) | intrinsics]
+    PI = flat.intr.shape[-1]
+    n = PI + 6 * flat.n_views
+    H = np.zeros((n, n))
+    off = flat.blk_offset
+    for b in range(flat.n_blocks):
+        Jb = J[2 * off[b]:2 * off[b + 1]]
+        idx = np.concatenate([PI + 6 * int(flat.blk_view[b]) + np.arange(6), np.arange(PI)])
+        H[np.ix_(idx, idx)] += Jb.T @ Jb
+    return H
+
+
+def weak_direction_report(orc, fa, fb, fixed=(4,)) -> dict:
+    """How the difference of two solutions fa, fb of the same problem sits in the spectrum of the Jacobi-scaled Hessian at fa:
+    condition number, Rayleigh quotient of the difference relative to the smallest eigenvalue, and the share of its (scaled) energy
+    inside the three weakest eigen-directions.  `fixed`: tangent coordinates held constant (4 = skew)."""
+    H = intrinsic_chain_hessian(orc, fa)
+    keep = np.ones(H.shape[0], bool)
+    keep[list(fixed)] = False
+    H = H[np.ix_(keep, keep)]
+    D = 1.0 / np.sqrt(np.diag(H))
+    Hs = H * D[:, None] * D[None, :]
+    w, V = np.linalg.eigh(Hs)
+    ds = tangent_delta(fa, fb)[keep] / D
+    c = V.T @ ds
+    return dict(kappa=float(w[-1] / w[0]), rayleigh_over_lmin=float(ds @ Hs @ ds / (ds @ ds) / w[0]) if ds @ ds > 0 else 0.0,
+                weak3_share=float((c[:3] ** 2).sum() / (c ** 2).sum()) if ds @ ds > 0 else 1.0)

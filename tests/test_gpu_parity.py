@@ -144,6 +144,39 @@ def test_lm_solve_matches_oracle(gpu_lib, oracle, kind, model, skw, okw, tol):
         assert helpers.param_diff(a.flat, b.flat) <= bar, (eps, sb.report)
 
 
+@pytest.mark.parametrize("seed", [3, 5])
+def test_scheimpflug_well_conditioned_scene_meets_the_1e9_bar(gpu_lib, oracle, seed):
+    """Scheimpflug at the north-star's parity bar (1e-9 relative): on a scene whose data determine every parameter
+    (synth.scene_intrinsics_wide: 1.3 m board, tilts up to 45 degrees, depth spread, sensor tilt 0.2 rad) the HIP engine and the
+    oracle agree to 1e-9.  Reference model: include/calib/models/scheimpflug.h:139-181."""
+    a, b = synth.scene_intrinsics_wide(seed=seed), synth.scene_intrinsics_wide(seed=seed)
+    o = options(epsilon=1e-12)
+    sa = helpers.oracle_solve(oracle, a.flat, o, threads=16)
+    sb = _gpu_solver(b.flat, o)
+    assert sa.success and sb.success and abs(sb.iterations - sa.iterations) <= 1
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-9, helpers.param_diff(a.flat, b.flat)
+
+
+@pytest.mark.parametrize("seed", [7, 11, 13])
+def test_scheimpflug_parity_gap_lies_in_the_flat_valley(gpu_lib, oracle, seed):
+    """The reference's test geometry leaves the Scheimpflug tilt / principal point / focal length valley nearly flat (condition
+    number of the Jacobi-scaled Hessian 1e8 .. 1e10).  Where the HIP engine and the oracle end further apart than rounding, the
+    test DEMONSTRATES that this is conditioning and not arithmetic: costs equal to 1e-12, the difference has > 95 % of its scaled
+    energy in the three weakest eigen-directions and a Rayleigh quotient within two orders of the smallest eigenvalue."""
+    a, b = synth.scene_intrinsics(7, model=1, noise_px=0.2, seed=seed), synth.scene_intrinsics(7, model=1, noise_px=0.2, seed=seed)
+    o = options(epsilon=1e-12, huber_delta=-1.0)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = _gpu_solver(b.flat, o)
+    assert sa.success and sb.success and abs(sb.iterations - sa.iterations) <= 3
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    rep = helpers.weak_direction_report(oracle, a.flat, b.flat)
+    gap = helpers.param_diff(a.flat, b.flat)
+    assert rep["kappa"] > 1e8 and gap <= 1e-6, (rep, gap)
+    if gap > 1e-10:
+        assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, (rep, gap)
+
+
 def test_covariance_matches_oracle(gpu_lib, oracle):
     for mk, okw in ((lambda: synth.scene_intrinsics(6, noise_px=0.2), {}),
                     (lambda: synth.scene_extrinsics(4, 2, noise_px=0.2), {}),
@@ -629,6 +662,120 @@ def test_full_size_c2_properties(gpu_lib):
     act = sig > 0
     assert (err[act] <= 6.0 * sig[act]).all(), (err, sig)  # within 6 sigma of the engine's own covariance
     assert err[:4].max() < 0.2  # and well under a fifth of a pixel in fx, fy, cx, cy
+
+
+def test_full_size_c3_properties(gpu_lib, lm_mode):
+    """BASELINE configs[2] at FULL size — 4000 views x 8 cameras x 5000 points = 1.6e8 observations, 32 000 residual blocks,
+    optimize_extrinsics (src/estimation/optim/extrinsics.cpp:174-196) — through the size-independent properties of the path
+    (the oracle would need an hour).  Mode A's 59 GB output stays in HBM: sampled blocks come back through the block-range
+    fetch and must reproduce Mode B's (moment-form) J^T J and J^T r; evaluation and the whole solve are bitwise repeatable; the
+    LM converges at the reference's epsilon = 1e-9 and lands within 6 sigma of the engine's own shared covariance."""
+    if lm_mode == "resident":
+        pytest.skip("one pass at this size (the resident kernel never takes a problem of 1.6e8 observations)")
+    sc = synth.scene_extrinsics(4000, 8, rows=50, cols=100, spacing=0.008, noise_px=0.2, seed=137)
+    assert sc.flat.n_obs == 160_000_000 and sc.flat.n_blocks == 32_000
+    start = (sc.flat.intr.copy(), sc.flat.cam_pose.copy(), sc.flat.view_pose.copy())
+    with optim.ReprojHandle(sc.flat) as h:
+        h.eval()
+        nb = h.block_normal_eq()
+        assert np.array_equal(nb, h.block_normal_eq())  # no atomics anywhere: bitwise repeatable
+        p = h.local_columns
+        nh = p * (p + 1) // 2
+        worst_g = worst_h = 0.0
+        for b in (0, 1, 7, 4097, 15_999, 16_000, 23_456, 31_999):
+            r, J = h.eval_fetch_blocks(b, b + 1)
+            assert r.shape == (10_000,) and J.shape == (10_000, p)
+            g, H = J.T @ r, J.T @ J
+            worst_g = max(worst_g, np.abs(g - nb[b, nh:nh + p]).max() / max(1.0, np.abs(g).max()))
+            d = np.sqrt(np.diag(H))
+            ok = np.outer(d, d)[np.triu_indices(p)] > 0
+            worst_h = max(worst_h, (np.abs(H[np.triu_indices(p)] - nb[b, :nh])[ok] / np.outer(d, d)[np.triu_indices(p)][ok]).max())
+            assert abs(float(r @ r) - nb[b, -1]) <= 1e-11 * nb[b, -1]
+        assert worst_g <= 1e-9 and worst_h <= 1e-10, (worst_g, worst_h)
+        c = h.cost(-1.0)
+        assert abs(c - 0.5 * nb[:, -1].sum()) <= 1e-10 * c
+        o = options(compute_covariance=0)
+        s = h.solve(o)
+        assert s.success and s.iterations <= 15, s.report
+        first = (sc.flat.intr.copy(), sc.flat.cam_pose.copy(), sc.flat.view_pose.copy())
+        xs = h.solve_stats()
+        # one exchange point per LM step (a no-op on a single rank): the initial system, one per trial point, one more only for a
+        # rejected step, a radius miss, or a step accepted after a plain trial
+        assert xs["speculative_steps"] >= 1 and xs["speculation_hits"] >= 1
+        assert xs["allreduce_calls"] == 1 + s.iterations + xs["speculation_misses"] + xs["rejected_steps"] + (
+            s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"])
+        cs = h.covariance_shared(o)
+        cs_err = gpu_lib.cba_last_error().decode() if cs is None else ""
+        # the same solve again from the same start on the same handle: bitwise identical end state
+        h.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
+        s2 = h.solve(o)
+        assert (s2.iterations, s2.final_cost) == (s.iterations, s.final_cost)
+        assert all(np.array_equal(a, b) for a, b in zip(first, (sc.flat.intr, sc.flat.cam_pose, sc.flat.view_pose)))
+    err = np.abs(sc.flat.intr - sc.gt_intr)
+    assert err[:, :4].max() < 0.1  # fx, fy, cx, cy: 2e7 observations per camera at 0.2 px
+    assert err[:, 5].max() < 2e-4 and err[:, 8:10].max() < 2e-5  # k1, p1, p2
+    if cs is None:
+        # ceres::Covariance (SPARSE_QR) calls a column dependent when its R diagonal is below SuiteSparseQR's default tolerance
+        # 20 (m + n) eps max|J_j|, which grows with the row count: at m = 3.2e8 rows it is ~20 (in pixels per unit parameter) and
+        # the k3 pivot of a 0.8 m board at 2 m lies below it - the reference would return no covariance for this problem either
+        assert "rank deficient" in cs_err, cs_err
+    else:
+        sig = np.sqrt(np.diag(cs))[:err.size]
+        act = sig > 0
+        assert (err.reshape(-1)[act] <= 6.0 * sig[act]).all(), (err.reshape(-1)[act] / sig[act]).max()
+
+
+def test_exact_c1_shape_against_the_oracle(gpu_lib, oracle):
+    """BASELINE configs[0] exactly: one pinhole intrinsic refinement, 20 views x 88 points (8 x 11 target, 0.02 m pitch, the
+    reference's own test geometry, intrinsics_optimize_test.cpp:8-61), with the reference's defaults (epsilon = 1e-9) and at
+    epsilon = 1e-12: same termination and iteration count as the oracle, parameters to 1e-9."""
+    for eps, tol in ((1e-9, 1e-7), (1e-12, 1e-9)):
+        a = synth.scene_intrinsics(20, noise_px=0.2)
+        b = synth.scene_intrinsics(20, noise_px=0.2)
+        assert a.flat.n_obs == 20 * 88
+        o = options(epsilon=eps)
+        sa = helpers.oracle_solve(oracle, a.flat, o, threads=16)
+        with optim.ReprojHandle(b.flat) as h:
+            h.eval()
+            r1, J1 = h.eval_fetch()
+            sb = h.solve(o)
+        r0, J0 = helpers.oracle_eval(oracle, synth.scene_intrinsics(20, noise_px=0.2).flat)
+        assert np.abs(r0 - r1).max() <= 1e-9 and (np.abs(J0 - J1) / np.maximum(1.0, np.abs(J0))).max() <= 1e-9
+        assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 1, (sa.report, sb.report)
+        assert abs(sb.final_cost - sa.final_cost) <= 1e-10 * sa.final_cost
+        assert helpers.param_diff(a.flat, b.flat) <= tol, helpers.param_diff(a.flat, b.flat)
+
+
+def test_full_size_c5_fp32_study(gpu_lib, lm_mode):
+    """BASELINE configs[4] at FULL size (Scheimpflug intrinsics, 1000 views x 10 000 points = 1e7 observations, 0.2 px noise):
+    the fp32 kernels against the fp64 ones.  fp32 Mode A rows agree with fp64 to a few fp32 ulps of a pixel coordinate, the
+    fp32 LM ends at the same cost to 1e-5 relative and moves the intrinsics far less than their own standard deviation —
+    while staying orders of magnitude above the 1e-9 parity bar, which therefore remains an fp64-only claim."""
+    if lm_mode == "resident":
+        pytest.skip("one pass at this size")
+    res = {}
+    for scalar in (0, 1):
+        sc = synth.scene_intrinsics(1000, rows=100, cols=100, spacing=0.008, noise_px=0.2, model=capi.CAMERA_SCHEIMPFLUG, seed=5)
+        with optim.ReprojHandle(sc.flat) as h:
+            h.set_scalar(scalar)
+            h.eval()
+            if scalar:
+                r, J = h.eval_fetch_f32()
+            else:
+                r, J = h.eval_fetch_blocks(0, 8)
+            s = h.solve(options(compute_covariance=0))
+            cs = h.covariance_shared(options()) if not scalar else None
+        res[scalar] = (sc, np.asarray(r[:2 * 80_000], dtype=np.float64), np.asarray(J[:2 * 80_000], dtype=np.float64), s, cs)
+    (s64, r64, J64, st64, cs), (s32, r32, J32, st32, _) = res[0], res[1]
+    assert st64.success and st32.success
+    assert np.abs(r32 - r64).max() <= 2e-4  # fp32 ulp at ~1e3 px is 6e-5 px
+    assert (np.abs(J32 - J64) / np.maximum(1.0, np.abs(J64))).max() <= 1e-4
+    assert abs(st32.final_cost - st64.final_cost) <= 1e-5 * st64.final_cost
+    d = np.abs(s32.flat.intr - s64.flat.intr).reshape(-1)
+    sig = np.sqrt(np.diag(cs))[:d.size]
+    act = sig > 0
+    assert (d[act] <= 1.0 * sig[act]).all(), (d[act] / sig[act]).max()  # fp32 moves every intrinsic by less than one sigma ...
+    assert helpers.rel_diff(s64.flat.intr, s32.flat.intr) > 1e-8               # ... and by far more than the fp64 parity bar
 
 
 def test_c3_shaped_moment_mode_b_equals_direct_mode_b(gpu_lib, monkeypatch):

@@ -185,6 +185,77 @@ def test_schur_lm_driver_matches_dense_oracle(oracle, hostmath, kind, model, skw
     assert helpers.param_diff(a.flat, b.flat) <= tol
 
 
+def hm_solve_ex(hostmath, flat, o, speculate):
+    d = flat.struct()
+    s = CbaSummary()
+    xs = (C.c_int64 * 6)()
+    st = hostmath.hm_reproj_solve_ex(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, speculate, C.byref(s), xs)
+    assert st == 0, hostmath.hm_last_error()
+    return s, [int(v) for v in xs]
+
+
+@pytest.mark.parametrize("kind,model,noise,okw", [("intr", 0, 0.2, {}), ("intr", 1, 0.2, {}), ("ext", 0, 0.2, {}), ("ext", 0, 0.0, dict(optimize_intrinsics=0)),
+                                                   ("bundle", 0, 0.2, dict(optimize_intrinsics=1)), ("bundle", 1, 0.0, dict(optimize_intrinsics=1)),
+                                                   ("intr", 0, 0.2, dict(huber_delta=0.2))])
+def test_speculative_steps_take_the_same_decisions_as_the_two_exchange_sequence(hostmath, kind, model, noise, okw):
+    """The LM linearises every trial point ahead of the accept decision so that the step statistics and the next system travel
+    in ONE all-reduce.  That changes when things are computed, not what is decided: termination, iteration
+    and accepted-step counts equal those of the plain sequence (trial cost, then a new linearisation), parameters agree to
+    rounding, and the number of exchanges is the one the protocol promises."""
+    mk = {"intr": lambda: synth.scene_intrinsics(10, model=model, spacing=0.08, noise_px=noise),
+          "ext": lambda: synth.scene_extrinsics(6, 3, model=model, spacing=0.08, noise_px=noise),
+          "bundle": lambda: synth.scene_bundle(12, 2, model=model, spacing=0.04, noise_px=noise)}[kind]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **okw)
+    sa, xa = hm_solve_ex(hostmath, a.flat, o, 0)
+    sb, xb = hm_solve_ex(hostmath, b.flat, o, 1)
+    assert (sb.termination, sb.iterations, sb.successful_steps) == (sa.termination, sa.iterations, sa.successful_steps), (sa.report, sb.report)
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * max(1.0, sa.final_cost) + 1e-20
+    assert helpers.param_diff(a.flat, b.flat) <= (1e-8 if model == 1 else 1e-11)
+    calls, _n, spec, hits, misses, rejected = xb
+    assert xa[2] == 0 and spec >= 1 and hits + misses <= spec
+    # plain: every iteration exchanges the trial statistics and then a system (2), plus the initial system
+    assert xa[0] == 1 + 2 * sa.iterations - (1 if sa.success and sa.iterations > 0 and "tolerance" in sa.report.decode() and "Gradient" not in sa.report.decode() else 0)
+    # speculative: one exchange per trial point; one more only for a rejected step, a radius miss, or a step accepted after a plain trial
+    assert calls == 1 + sb.iterations + misses + rejected + (sb.successful_steps - hits - misses)
+    assert calls < xa[0]
+
+
+@pytest.mark.parametrize("seed", [3, 5])
+def test_scheimpflug_well_conditioned_scene_meets_the_1e9_bar(oracle, hostmath, seed):
+    """Scheimpflug parity at the north-star's bar.  On a scene whose data determine every parameter (large board, tilts up to 45
+    degrees, depth spread, sensor tilt 0.2 rad: synth.scene_intrinsics_wide) the Schur-reduced product driver and the dense oracle
+    agree to 1e-9 relative — in fact to rounding."""
+    a, b = synth.scene_intrinsics_wide(seed=seed), synth.scene_intrinsics_wide(seed=seed)
+    o = options(epsilon=1e-12)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sa.success and sb.success and sb.iterations == sa.iterations
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-9
+    assert helpers.weak_direction_report(oracle, a.flat, b.flat)["kappa"] < 1e8  # an order or more below the narrow scenes
+
+
+@pytest.mark.parametrize("seed", [7, 11, 13])
+def test_scheimpflug_parity_gap_lies_in_the_flat_valley(oracle, hostmath, seed):
+    """On the reference's test geometry (8 x 11 board of 0.2 m, mild tilts, one distance) the Scheimpflug tilt / principal point /
+    focal length valley is nearly flat: the Jacobi-scaled Hessian has condition number 1e8 .. 1e10, so two correct solvers that
+    differ by rounding end a few 1e-9 apart IN THAT VALLEY.  Shown, not asserted in a comment: the costs agree to 1e-12, and the
+    difference of the two solutions has > 95 % of its scaled energy in the three weakest eigen-directions, with a Rayleigh quotient
+    within two orders of the smallest eigenvalue (eight or more orders below the largest)."""
+    a, b = synth.scene_intrinsics(7, model=1, noise_px=0.2, seed=seed), synth.scene_intrinsics(7, model=1, noise_px=0.2, seed=seed)
+    o = options(epsilon=1e-12, huber_delta=-1.0)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sa.success and sb.success and abs(sb.iterations - sa.iterations) <= 2
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    rep = helpers.weak_direction_report(oracle, a.flat, b.flat)
+    assert rep["kappa"] > 1e8, rep
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-7
+    if helpers.param_diff(a.flat, b.flat) > 1e-12:
+        assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, rep
+
+
 def test_lm_semantics(oracle, hostmath):
     # max_iterations hit => NO_CONVERGENCE => success False (ceresutils.h:42)
     sc = synth.scene_intrinsics(8, noise_px=0.2)

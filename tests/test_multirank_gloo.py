@@ -64,12 +64,14 @@ def _worker(rank, world, port, kind, okw, outdir):
     d = flat.struct()
     s = CbaSummary()
     o = helpers.options(epsilon=1e-12, **okw)
-    st = hm.hm_reproj_solve(C.byref(d), C.byref(o), cb, None, world, rank, C.byref(s))
+    xs = (C.c_int64 * 6)()
+    st = hm.hm_reproj_solve_ex(C.byref(d), C.byref(o), cb, None, world, rank, -1, C.byref(s), xs)
     assert st == 0, hm.hm_last_error()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), intr=flat.intr, cam=flat.cam_pose if flat.cam_pose is not None else np.zeros(0),
              view=flat.view_pose if flat.view_pose is not None else np.zeros(0),
              target=flat.target_pose if flat.target_pose is not None else np.zeros(0), first=flat.first_view_global,
-             iters=s.iterations, cost=s.final_cost, term=s.termination, ncalls=len(calls))
+             iters=s.iterations, cost=s.final_cost, term=s.termination, ncalls=len(calls), xs=np.array(list(xs)),
+             accepted=s.successful_steps, sizes=np.array(calls))
     dist.destroy_process_group()
 
 
@@ -101,6 +103,15 @@ def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw):
             assert helpers.rel_diff(ref.cam_pose, r["cam"]) <= 1e-9
         if ref.target_pose is not None:
             assert helpers.rel_diff(ref.target_pose, r["target"]) <= 1e-9
+        # ONE packed all-reduce per LM step.  Every trial point is one exchange (speculative steps carry
+        # the next system with their statistics); beyond those: the initial system, one re-elimination per rejected step and per
+        # accepted step whose radius was not the predicted one, one new system per step accepted after a plain (cost-only) trial.
+        calls, _doubles, spec, hits, misses, rejected = (int(v) for v in r["xs"])
+        iters, accepted = int(r["iters"]), int(r["accepted"])
+        assert calls == int(r["ncalls"]) and spec >= 1 and hits >= 1 and hits + misses <= spec
+        accepted_plain = accepted - hits - misses
+        assert calls == 1 + iters + misses + rejected + accepted_plain
+        assert calls <= iters + 1 + misses + 2 * rejected  # one collective per step, plus one per rejection / radius miss
     # replicated blocks are bit-identical across ranks (same all-reduced sums, same host arithmetic)
     assert np.array_equal(res[0]["intr"], res[1]["intr"]) and np.array_equal(res[0]["cam"], res[1]["cam"])
     if ref.view_pose is not None:
