@@ -313,7 +313,7 @@ __global__ void k_accept(int64_t n_shared, const double* __restrict__ shared_tri
 struct PackArgs {
     int64_t off_stats, off_cam, off_cost, off_nfail, off_S, off_g, off_gmax;
     int n, n_tiles, n_ranks, rank, n_cam_doubles;
-    int has_blocks, has_schur, has_stats;
+    int has_blocks /* camera sums are in the pack */, has_cost /* stat[4] holds the cost */, has_schur, has_stats;
 };
 __global__ __launch_bounds__(256) void k_pack(PackArgs a, const double* __restrict__ stat /*[0..4): step2, xnorm2, gd, dHd; [4]: cost*/,
                                               const double* __restrict__ tiles /*[pairs*4096 | g | gmax, nfail]*/, double* __restrict__ pack) {
@@ -335,14 +335,38 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const double* __restri
     if (tid < a.n_ranks) pack[a.off_gmax + tid] = (a.has_schur && tid == a.rank) ? tiles[sw + a.n] : 0.0;
     if (tid == 0) {
         pack[a.off_nfail] = a.has_schur ? tiles[sw + a.n + 1] : 0.0;
-        pack[a.off_cost] = a.has_blocks ? stat[4] : 0.0;
-        pack[a.off_stats + 0] = a.has_stats ? stat[2] : 0.0;  // PackLayout::GD
-        pack[a.off_stats + 1] = a.has_stats ? stat[3] : 0.0;  // DHD
-        pack[a.off_stats + 2] = a.has_stats ? stat[0] : 0.0;  // STEP2
-        pack[a.off_stats + 3] = a.has_stats ? stat[1] : 0.0;  // XNORM2
-        pack[a.off_stats + 4] = (a.has_stats && a.has_blocks) ? stat[4] : 0.0;  // TRIAL_COST
+        pack[a.off_cost] = a.has_cost ? stat[4] : 0.0;
+        // has_stats: 1 = a trial step (stat[2], stat[3] = the views' g^T d, d^T H d), 2 = a line-search sample (stat[2] = their slope)
+        pack[a.off_stats + 0] = a.has_stats == 1 ? stat[2] : 0.0;  // PackLayout::GD
+        pack[a.off_stats + 1] = a.has_stats == 1 ? stat[3] : 0.0;  // DHD
+        pack[a.off_stats + 2] = a.has_stats ? stat[0] : 0.0;       // STEP2
+        pack[a.off_stats + 3] = a.has_stats ? stat[1] : 0.0;       // XNORM2
+        pack[a.off_stats + 4] = (a.has_stats && a.has_cost) ? stat[4] : 0.0;  // TRIAL_COST
+        pack[a.off_stats + 5] = a.has_stats == 2 ? stat[2] : 0.0;  // SLOPE
     }
     if (!a.has_blocks && tid < a.n_cam_doubles) pack[a.off_cam + tid] = 0.0;
+}
+
+// line search sample (line_search.hpp): trial poses at step size a along the last back-substituted step; stats [n_views][4] =
+// { |xt - x|^2, |x|^2, slope share (k_view_slope, or 0), 0 }
+__global__ void k_scale_step(int n_views, double a, const int32_t* __restrict__ fixed, const double* __restrict__ x,
+                             const double* __restrict__ delta_p, double* __restrict__ xt, double* __restrict__ stats) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_views) return;
+    double o2[2];
+    scale_step_view_body(fixed[v] != 0, a, x + 7 * static_cast<int64_t>(v), delta_p + 6 * static_cast<int64_t>(v), xt + 7 * static_cast<int64_t>(v), o2);
+    stats[4 * static_cast<int64_t>(v)] = o2[0];
+    stats[4 * static_cast<int64_t>(v) + 1] = o2[1];
+    stats[4 * static_cast<int64_t>(v) + 2] = 0.0;
+    stats[4 * static_cast<int64_t>(v) + 3] = 0.0;
+}
+__global__ void k_view_slope(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
+                             const double* __restrict__ blk_acc, const double* __restrict__ blk_w, const int32_t* __restrict__ fixed,
+                             const double* __restrict__ delta_p, double* __restrict__ stats) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_views) return;
+    stats[4 * static_cast<int64_t>(v) + 2] = view_slope_body(d, static_cast<int>(link_off[v + 1] - link_off[v]), link_blk + link_off[v], blk_acc,
+                                                              blk_w, fixed[v] != 0, delta_p + 6 * static_cast<int64_t>(v));
 }
 
 // an accepted SPECULATIVE step: besides the parameter copies, the trial linearisation's block sums and weights become current
@@ -548,12 +572,12 @@ struct HipBackend final : Backend {
     }
     // ---- packed systems (lm_core.hpp): assembled on the device, ONE all-reduce in place on the engine's stream (RCCL), one
     // device-to-host copy of the reduced buffer, one synchronisation ---------------------------------------------------------------
-    PackArgs pack_args(const PackLayout& L, bool has_blocks, bool has_schur, bool has_stats) const {
+    PackArgs pack_args(const PackLayout& L, bool has_blocks, bool has_schur, int has_stats, int has_cost) const {
         const Structure& s = st.s;
         PackArgs a;
         a.off_stats = L.stats; a.off_cam = L.cam; a.off_cost = L.cost; a.off_nfail = L.nfail; a.off_S = L.S; a.off_g = L.g; a.off_gmax = L.gmax;
         a.n = s.nsh; a.n_tiles = st.n_tiles; a.n_ranks = L.n_ranks; a.rank = e.rank; a.n_cam_doubles = s.n_cams * s.NACC;
-        a.has_blocks = has_blocks; a.has_schur = has_schur; a.has_stats = has_stats;
+        a.has_blocks = has_blocks; a.has_schur = has_schur; a.has_stats = has_stats; a.has_cost = has_cost < 0 ? has_blocks : has_cost;
         return a;
     }
     void ensure_pack(const PackLayout& L) {
@@ -569,9 +593,9 @@ struct HipBackend final : Backend {
     // Where the pack is assembled: in device memory when RCCL reduces it there in place; otherwise the kernels write it straight
     // into page-locked host memory (no copy command before the one synchronisation, as the unpacked stages do).
     double* pack_target() { return e.rccl_comm ? st.pack_dev.p : st.pin_packed.p; }
-    void enqueue_pack(const PackLayout& L, bool has_blocks, bool has_schur, bool has_stats) {
+    void enqueue_pack(const PackLayout& L, bool has_blocks, bool has_schur, int has_stats, int has_cost = -1) {
         const int64_t work = std::max<int64_t>({static_cast<int64_t>(st.s.nsh) * st.s.nsh, static_cast<int64_t>(st.s.n_cams) * st.s.NACC, L.n_ranks, 1});
-        hipLaunchKernelGGL(k_pack, dim3(nblk(work, 256)), dim3(256), 0, e.stream, pack_args(L, has_blocks, has_schur, has_stats),
+        hipLaunchKernelGGL(k_pack, dim3(nblk(work, 256)), dim3(256), 0, e.stream, pack_args(L, has_blocks, has_schur, has_stats, has_cost),
                            st.stat_dev.p, st.sys_tiles.p, pack_target());
         CBA_HIP(hipGetLastError());
     }
@@ -599,7 +623,7 @@ struct HipBackend final : Backend {
         st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
         if (q1) enqueue_normal_eq(huber, 0, pack_target() + L.cam, st.stat_dev.p + 4);
         if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, q1, q2, false);
+        enqueue_pack(L, q1, q2, 0);
         exchange(L.cam, L.size - L.cam, ar, pack);
         e.active = 0;
     }
@@ -611,7 +635,7 @@ struct HipBackend final : Backend {
         st.pin_lmp.p[0] = radius;
         st.pin_lmp.p[1] = 0.0;
         if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, s.n_blocks != 0, q2, false);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
+        enqueue_pack(L, s.n_blocks != 0, q2, 0);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
         exchange(L.nfail, L.gmax - L.nfail, ar, pack);
     }
     bool sys_step(const double* delta_sh, double huber, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
@@ -648,10 +672,50 @@ struct HipBackend final : Backend {
         }
         std::swap(e.blk_acc.p, e.blk_acc_alt.p);
         std::swap(e.blk_w.p, e.blk_w_alt.p);
-        enqueue_pack(L, q1, q2, true);
+        enqueue_pack(L, q1, q2, 1);
         exchange(0, L.size, ar, pack);
         e.active = 1;
         return true;
+    }
+    void line_eval(double a, double huber, bool want_slope, const PackLayout& L, const AllReduce& ar, int rank, double* pack) override {
+        (void)rank;
+        const Structure& s = st.s;
+        ensure_pack(L);
+        if (want_slope && e.blk_acc_alt.n < e.blk_acc.n) { e.blk_acc_alt.alloc(e.blk_acc.n); e.blk_w_alt.alloc(e.blk_w.n); }
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta, e.stream);  // the shared blocks at this step size (staged by upload_shared(1))
+        if (q2)
+            hipLaunchKernelGGL(k_scale_step, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, s.n_views, a, e.view_fixed.p, e.view[0].p,
+                               st.view_delta.p, e.view[1].p, st.view_stats.p);
+        if (q1 && want_slope) {  // linearise at the sample into the second set of block sums (the current set stays valid)
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+            try {
+                enqueue_normal_eq(huber, 1, pack_target() + L.cam, st.stat_dev.p + 4);
+                if (q2)
+                    hipLaunchKernelGGL(k_view_slope, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                                       st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.view_delta.p, st.view_stats.p);
+            } catch (...) {
+                std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+                std::swap(e.blk_w.p, e.blk_w_alt.p);
+                throw;
+            }
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+        } else if (q1) {  // the cost alone (Mode R)
+            launch_block_consts(e, 1);
+            launch_resid(e);
+            launch_cost(e, huber, st.stat_dev.p + 4);
+        }
+        if (q2)
+            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p, static_cast<const double*>(nullptr),
+                               st.stat_dev.p);
+        else
+            CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        CBA_HIP(hipGetLastError());
+        enqueue_pack(L, q1 && want_slope, false, 2, q1 ? 1 : 0);
+        exchange(0, L.size, ar, pack);
+        e.active = 1;
     }
     void accept_step() override {
         const int64_t n_shared = static_cast<int64_t>(e.pk_delta), n_view = static_cast<int64_t>(e.h_view.size());
@@ -795,9 +859,9 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     CBA_HIP(hipStreamSynchronize(e.stream));
 }
 
-void solve_stats(const Engine& e, int64_t stats6[6]) {
+void solve_stats(const Engine& e, int64_t stats8[8]) {
     const HipLMState* st = reinterpret_cast<const HipLMState*>(e.lm_state);
-    for (int k = 0; k < 6; ++k) stats6[k] = st ? st->xs[k] : 0;
+    for (int k = 0; k < 8; ++k) stats8[k] = st ? st->xs[k] : 0;
 }
 
 void set_lm_mode(Engine& e, int mode) {
@@ -910,9 +974,8 @@ void warm_lm(Engine& e) {
 
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
     if (resident_lm_eligible(e, o)) {  // small problem: the whole iteration in one kernel launch
-        resident_lm_solve(e, o, out);
-        for (int k = 0; k < 6; ++k) lm_state(e)->xs[k] = 0;
-        return;
+        for (int k = 0; k < 8; ++k) lm_state(e)->xs[k] = 0;
+        if (resident_lm_solve(e, o, out)) return;
     }
     HipBackend be(e, *lm_state(e));
     LMDriver drv = make_driver(e, be);
@@ -921,7 +984,7 @@ void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
         const ExchangeStats& x = drv.exchange_stats();
         int64_t* xs = lm_state(e)->xs;
         xs[0] = x.allreduce_calls; xs[1] = x.allreduce_doubles; xs[2] = x.speculative_steps; xs[3] = x.speculation_hits;
-        xs[4] = x.speculation_misses; xs[5] = x.rejected_steps;
+        xs[4] = x.speculation_misses; xs[5] = x.rejected_steps; xs[6] = x.line_searches; xs[7] = x.line_search_evaluations;
     }
     // leave copy 0 on the device equal to the host state
     e.intr[0].upload(e.h_intr.data(), e.h_intr.size(), e.stream);

@@ -713,10 +713,10 @@ cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode) {
     return guarded([&] { set_lm_mode(*as_engine(h), mode); });
 }
 
-cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats6[6]) {
+cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats8[8]) {
     return guarded([&] {
-        if (!h || !stats6) throw std::invalid_argument("null argument");
-        solve_stats(*reinterpret_cast<const Engine*>(h), stats6);
+        if (!h || !stats8) throw std::invalid_argument("null argument");
+        solve_stats(*reinterpret_cast<const Engine*>(h), stats8);
     });
 }
 

@@ -246,7 +246,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records = f
 void destroy_lm_state(Engine& e);
 void warm_lm(Engine& e);
 void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
-void solve_stats(const Engine& e, int64_t stats6[6]);  // ExchangeStats of the last host-driven solve
+void solve_stats(const Engine& e, int64_t stats8[8]);  // ExchangeStats of the last host-driven solve
 void set_lm_mode(Engine& e, int mode);  // 0 host-driven iteration, 1 automatic (default), 2 resident kernel whenever it can run the problem
 void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
 int64_t covariance_dim(const Engine& e);

@@ -7,7 +7,7 @@
 // owns a tile; wavefront p accumulates part p for ALL observations of the tile but evaluates the rows of only every NP-th
 // 64-observation chunk; the rows (14 / 11 double2 per observation) reach the other wavefronts of the workgroup through LDS:
 //
-//     per group of NP chunks, wavefront p:   evaluate rows of chunk p -> LDS[p], accumulate them
+//     per group of NP chunks (NP = 2 .. 4 by form and camera model, see the launcher), wavefront p:   evaluate rows of chunk p -> LDS[p], accumulate them
 //                                            barrier
 //                                            for q != p: read rows of chunk q from LDS[q] (same lane), accumulate
 //                                            barrier
@@ -16,6 +16,8 @@
 // Vector work per observation: R + NP * A instead of NP * (R + A)  (R rows, A accumulate share): 376 instead of 526 instructions
 // for the one-pose chain, 409 instead of 669 for the moment form.  Results equal the per-part launches bit for bit: the same
 // products are added to the same accumulators in the same observation order (chunks in order, lanes fixed).
+#include <cstdlib>
+
 #include "engine.hpp"
 #include "mode_b.hpp"
 #include "reproj_math.hpp"
@@ -57,11 +59,14 @@ struct MomentForm {
 };
 
 template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW + 1) / 2; };
+// NBUF = 2: the row buffer is doubled, group g uses half g & 1, and ONE barrier per group suffices (a wavefront overwrites half h
+// only after passing the barrier of the group in between, i.e. after every wavefront has read half h); NBUF = 1: two barriers.
 
 // the work of wavefront PART of the workgroup
-template <class FORM, int PART, typename T>
+// ABL (timing-only ablations, WRONG results): 1 = no barriers, 2 = no LDS reads (the own rows are accumulated NP times), 3 = both
+template <class FORM, int PART, int NBUF, typename T, int ABL = 0>
 __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
-                                               const T* u, const T* v, v2f64 (*sh)[ShareDims<FORM>::NR2][64], double* out) {
+                                               const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out) {
     constexpr int NP = FORM::NPARTS, NROW = FORM::NROW, NR2 = ShareDims<FORM>::NR2;
     constexpr int NLOC = FORM::count(PART), NPAD = TransposeSum<16>::pad(NLOC);
     double acc[NPAD];
@@ -77,6 +82,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 #pragma unroll 1
     for (int g = 0; g < n_groups; ++g) {
         const int j = (g * NP + PART) * 64 + lane;
+        v2f64 (*sh)[NR2][64] = shb + (NBUF == 2 ? (g & 1) * NP : 0);
         T xn = T(0), yn = T(0), un = T(0), vn = T(0);
         if (j + 64 * NP < t.count) {  // the loads of the next group's own chunk, before this group's arithmetic
             const int64_t i = t.start + j + 64 * NP, k2 = t.xy_start + j + 64 * NP;
@@ -90,7 +96,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
             for (int k = 0; k < NR2; ++k) sh[PART][k][lane] = v2f64{w[2 * k], w[2 * k + 1]};
             FORM::template accumulate<PART>(w, static_cast<double>(xc), static_cast<double>(yc), acc);
         }
-        __syncthreads();  // every wavefront's rows of this group are in LDS
+        if (!(ABL & 1)) __syncthreads();  // every wavefront's rows of this group are in LDS
 #pragma unroll
         for (int q = 1; q < NP; ++q) {
             constexpr int dummy = 0; (void)dummy;
@@ -99,12 +105,12 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
             if (jo < t.count) {
                 double w[2 * NR2];
 #pragma unroll
-                for (int k = 0; k < NR2; ++k) { const v2f64 d = sh[p][k][lane]; w[2 * k] = d.x; w[2 * k + 1] = d.y; }
+                for (int k = 0; k < NR2; ++k) { const v2f64 d = sh[(ABL & 2) ? PART : p][k][(ABL & 2) ? 0 : lane]; w[2 * k] = d.x; w[2 * k + 1] = d.y; }
                 const double xo = static_cast<double>(X[t.xy_start + jo]), yo = static_cast<double>(Y[t.xy_start + jo]);
                 FORM::template accumulate<PART>(w, xo, yo, acc);
             }
         }
-        __syncthreads();  // before the next group overwrites the rows
+        if (NBUF == 1 && !(ABL & 1)) __syncthreads();  // before the next group overwrites the rows
         xc = xn; yc = yn; uc = un; vc = vn;
     }
     bool owner;
@@ -120,13 +126,13 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 }
 
 // one workgroup of FORM::NPARTS wavefronts per tile
-template <class FORM, typename T>
+template <class FORM, int NBUF, typename T, int ABL = 0>
 __global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
                                                                   const T* __restrict__ Y, const T* __restrict__ u, const T* __restrict__ v,
                                                                   int PI, double* __restrict__ partial) {
-    __shared__ v2f64 sh[FORM::NPARTS][ShareDims<FORM>::NR2][64];
+    __shared__ v2f64 sh[NBUF * FORM::NPARTS][ShareDims<FORM>::NR2][64];
     const int64_t w = blockIdx.x;
     if (w >= n_tiles) return;
     const Tile t = tiles[w];
@@ -137,38 +143,68 @@ __global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __r
     const T* ip = intr + static_cast<int64_t>(cam) * PI;
     const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double* out = partial + w * FORM::NTOT;
-    if (wave == 0) ne_shared_body<FORM, 0, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
-    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, T>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------
-template <class FORM, typename T>
+template <class FORM, int NBUF, typename T>
 static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
-    hipLaunchKernelGGL((k_ne_shared<FORM, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
+    hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
                        e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
 }
 
-template <class F64, class F32>
+template <class F64, class F32, int NBUF = 1>
 static void launch_both(Engine& e, double* rows) {
-    if (e.scalar) launch_form<F32, float>(e, e.bcf.p, e.intrf.p, e.sdf.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, rows);
-    else launch_form<F64, double>(e, e.bc.p, e.intr[e.active].p, e.sd.p, e.X.p, e.Y.p, e.u.p, e.v.p, rows);
+    if (e.scalar) launch_form<F32, NBUF, float>(e, e.bcf.p, e.intrf.p, e.sdf.p, e.Xf.p, e.Yf.p, e.uf.p, e.vf.p, rows);
+    else launch_form<F64, NBUF, double>(e, e.bc.p, e.intr[e.active].p, e.sd.p, e.X.p, e.Y.p, e.u.p, e.v.p, rows);
 }
 
 // the shared-rows kernel of this engine's chain / model writing one row per tile into `rows` (row stride = the form's NTOT);
 // returns false when there is no such kernel (the caller then uses the per-part launches)
 bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
     if (e.n_tilesB == 0) return true;
+    // experiment knobs (read once): CBA_MODEB_DPARTS = parts of the one-pose direct form (2, 3, 4);
+    // CBA_MODEB_VARIANT: bits 0-3 = parts of the moment form (2 .. 5), bit 4 = double-buffered rows, >= 32: timing-only ablations
+    // Defaults as measured (profiles/r02_modeb_variants.jsonl, ms per pass): one-pose chain, pinhole 2 parts 0.192 / 3: 0.235 / 4: 0.219;
+    // Scheimpflug 2: 0.303 / 3: 0.306 / 4: 0.265; moment form (C3 / 4), pinhole 2: 1.002 / 3: 0.955 / 4: 0.907 / 5: 1.618 (LDS-limited
+    // occupancy), double-buffered rows 0.961 (no gain: the barrier that remains is the one that costs).
+    static const int dparts_env = std::getenv("CBA_MODEB_DPARTS") ? std::atoi(std::getenv("CBA_MODEB_DPARTS")) : 0;
+    static const int variant = std::getenv("CBA_MODEB_VARIANT") ? std::atoi(std::getenv("CBA_MODEB_VARIANT")) : 4;
+    const int dparts = dparts_env ? dparts_env : (e.model == CAM_SCHEIMPFLUG ? 4 : 2);
     if (e.chain == CH_INTRINSIC) {
-        if (e.model == CAM_PINHOLE_BC)
-            launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>>(e, rows);
-        else
-            launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, float>>(e, rows);
+        if (e.model == CAM_PINHOLE_BC) {
+            if (dparts == 4) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, float>>(e, rows);
+            else if (dparts == 3) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, float>>(e, rows);
+            else launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>>(e, rows);
+        } else {
+            if (dparts == 4) launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<4>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<4>, float>>(e, rows);
+            else if (dparts == 3) launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<3>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<3>, float>>(e, rows);
+            else launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<2>, float>>(e, rows);
+        }
     } else {
         if (!e.modeb_moments) return false;
-        if (e.model == CAM_PINHOLE_BC) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
-        else launch_both<MomentForm<CAM_SCHEIMPFLUG, 4, double>, MomentForm<CAM_SCHEIMPFLUG, 4, float>>(e, rows);
+        if (e.model == CAM_PINHOLE_BC) {
+            if ((variant & 15) == 2) launch_both<MomentForm<CAM_PINHOLE_BC, 2, double>, MomentForm<CAM_PINHOLE_BC, 2, float>>(e, rows);
+            else if ((variant & 15) == 4) launch_both<MomentForm<CAM_PINHOLE_BC, 4, double>, MomentForm<CAM_PINHOLE_BC, 4, float>>(e, rows);
+            else if ((variant & 15) == 5) launch_both<MomentForm<CAM_PINHOLE_BC, 5, double>, MomentForm<CAM_PINHOLE_BC, 5, float>>(e, rows);
+            else if (variant & 16) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>, 2>(e, rows);
+            else if (variant >= 32 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
+                using F = MomentForm<CAM_PINHOLE_BC, 3, double>;
+                const dim3 g(static_cast<unsigned>(e.n_tilesB)), b(64 * 3);
+#define CBA_ABL(A) hipLaunchKernelGGL((k_ne_shared<F, 1, double, A>), g, b, 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p, e.intr[e.active].p, e.sd.p, \
+                                      e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.PI, rows)
+                if (variant == 33) CBA_ABL(1); else if (variant == 34) CBA_ABL(2); else CBA_ABL(3);
+#undef CBA_ABL
+            } else launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
+        } else {
+            if ((variant & 15) == 5) launch_both<MomentForm<CAM_SCHEIMPFLUG, 5, double>, MomentForm<CAM_SCHEIMPFLUG, 5, float>>(e, rows);
+            else if ((variant & 15) == 2) launch_both<MomentForm<CAM_SCHEIMPFLUG, 3, double>, MomentForm<CAM_SCHEIMPFLUG, 3, float>>(e, rows);
+            else launch_both<MomentForm<CAM_SCHEIMPFLUG, 4, double>, MomentForm<CAM_SCHEIMPFLUG, 4, float>>(e, rows);
+        }
     }
     CBA_HIP(hipGetLastError());
     return true;

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "dense.hpp"
+#include "line_search.hpp"
 #include "reproj_math.hpp"
 #include "schur_math.hpp"
 #include "structure.hpp"
@@ -46,11 +47,12 @@ using AllReduce = std::function<void(double*, int64_t)>;
 
 // Layout of the ONE packed buffer a linear solve exchanges between ranks: everything is a sum over ranks;
 // the private-gradient max travels as one slot per rank (sum of a one-hot vector), so a single sum-all-reduce serves all.
-//   [ step statistics (5) | per-camera weighted sums (n_cams * NACC) | cost | #failed views | S_schur (n*n) | g_schur (n) | gmax slots ]
+//   [ step statistics (6) | per-camera weighted sums (n_cams * NACC) | cost | #failed views | S_schur (n*n) | g_schur (n) | gmax slots ]
 struct PackLayout {
-    int64_t stats = 0, cam = 5, cost = 0, nfail = 0, S = 0, g = 0, gmax = 0, size = 0;
+    int64_t stats = 0, cam = 6, cost = 0, nfail = 0, S = 0, g = 0, gmax = 0, size = 0;
     int n = 0, n_ranks = 1;
-    enum { GD = 0, DHD = 1, STEP2 = 2, XNORM2 = 3, TRIAL_COST = 4 };
+    // GD, DHD: the views' share of g^T d and d^T H d; SLOPE (line_eval): the views' share of the directional derivative
+    enum { GD = 0, DHD = 1, STEP2 = 2, XNORM2 = 3, TRIAL_COST = 4, SLOPE = 5 };
     PackLayout() = default;
     PackLayout(const Structure& s, int ranks) : n(s.nsh), n_ranks(ranks) {
         cost = cam + static_cast<int64_t>(s.n_cams) * s.NACC;
@@ -128,6 +130,12 @@ struct Backend {
         return false;
     }
     virtual void accept_step() {}
+    // One sample of the line search (line_search.hpp) at x (+) a * step, where `step` is the step of the last trial() / sys_step()
+    // (its private part is still held by the backend; the shared part, already scaled, has been uploaded to copy 1): private trial
+    // poses = Plus(x, a * step_p), the cost there and, if want_slope, the linearisation there (into the second set of block sums)
+    // for the directional derivative along the step.  Fills TRIAL_COST, STEP2, XNORM2, SLOPE (private share) and, with want_slope,
+    // the camera sums; one all-reduce.
+    virtual void line_eval(double a, double huber, bool want_slope, const PackLayout& L, const AllReduce& ar, int rank, double* pack) = 0;
     // collectives the backend issued itself (device-side packing + RCCL): the driver adds them to its ExchangeStats
     int64_t device_allreduce_calls = 0, device_allreduce_doubles = 0;
 };
@@ -139,6 +147,8 @@ struct ExchangeStats {
     int32_t speculation_hits = 0;    // ... accepted with the predicted radius: ONE collective for the whole LM step
     int32_t speculation_misses = 0;  // ... accepted with another radius: one re-elimination + collective more
     int32_t rejected_steps = 0;
+    int32_t line_searches = 0;         // trust-region steps that failed the Armijo test at step size 1 (bounds-constrained problems)
+    int32_t line_search_evaluations = 0;
 };
 
 class LMDriver {
@@ -153,10 +163,12 @@ class LMDriver {
         };
         pack_.assign(static_cast<size_t>(L_.size), 0.0);
         if (const char* env = std::getenv("CBA_LM_SPECULATE")) speculate_ = std::atoi(env) != 0;
+        if (const char* env = std::getenv("CBA_LM_LINE_SEARCH")) line_search_ = std::atoi(env) != 0;
     }
     LMDriver(const LMDriver&) = delete;  // ar_ captures `this`
     LMDriver& operator=(const LMDriver&) = delete;
     void set_speculate(bool on) { speculate_ = on; }
+    void set_line_search(bool on) { line_search_ = on; }
     const ExchangeStats& exchange_stats() const { return xs_; }
 
     // ---- masks: which blocks Ceres would hold constant ----------------------------------------
@@ -275,6 +287,45 @@ class LMDriver {
                     }
                     model_change = -(st.gd + gd_sh) - 0.5 * (st.dHd + dHd_sh);
                     if (!(model_change > 0.0) || !std::isfinite(model_change)) valid = false;
+                    // Ceres' projected line search on bounds-constrained problems (line_search.hpp).  The trial point just evaluated
+                    // IS its first sample (step size 1); only a step that fails the Armijo test there is searched — and then scaled.
+                    const double slope0 = st.gd + gd_sh;
+                    if (valid && constrained_ && line_search_ && !(std::isfinite(st.cost) && st.cost <= cost_ + 1e-4 * slope0)) {
+                        ++xs_.line_searches;
+                        speculated = false;  // whatever was linearised at step size 1 is not the point the step will end at
+                        const std::vector<double> full = delta;
+                        double dmax = 0.0;  // Ceres: max-norm of the whole direction; the views' part is bounded by the shared part's
+                        for (double d : full) dmax = std::max(dmax, std::fabs(d));  // scale here (it only gates a 1e-9 cut-off)
+                        std::vector<double> scaled(n);
+                        auto sample = [&](double a, bool with_slope) {
+                            for (int i = 0; i < n; ++i) scaled[i] = a * full[i];
+                            shared_plus(scaled, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
+                            be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
+                            be_.line_eval(a, huber, with_slope, L_, ar_, rank_, pack_.data());
+                            LineSample ls;
+                            ls.step = a;
+                            ls.value = pack_[L_.stats + PackLayout::TRIAL_COST];
+                            ls.has_value = std::isfinite(ls.value);
+                            if (with_slope && ls.has_value) {
+                                const std::vector<double> cam_acc(pack_.begin() + L_.cam, pack_.begin() + L_.cost);
+                                std::vector<double> Ht(static_cast<size_t>(n) * n), gt(n);
+                                assemble_shared(cam_acc, Ht, gt);
+                                double sl = pack_[L_.stats + PackLayout::SLOPE];
+                                for (int i = 0; i < n; ++i) sl += gt[i] * full[i];  // (full is zero on inactive columns)
+                                ls.slope = sl;
+                                ls.has_slope = std::isfinite(sl);
+                            }
+                            return ls;
+                        };
+                        int evals = 0;
+                        double a = armijo_line_search(cost_, slope0, dmax, sample, &evals);
+                        xs_.line_search_evaluations += evals;
+                        if (!(a > 0.0)) { a = 1.0; (void)sample(1.0, false); }  // search failed: the full step, re-established on the device
+                        for (int i = 0; i < n; ++i) delta[i] = a * full[i];
+                        st.cost = pack_[L_.stats + PackLayout::TRIAL_COST];
+                        st.step2 = pack_[L_.stats + PackLayout::STEP2];
+                        st.xnorm2 = pack_[L_.stats + PackLayout::XNORM2];
+                    }
                 }
                 if (!valid) {
                     if (++invalid >= 5) { done(CBA_TERM_FAILURE, "Number of consecutive invalid steps more than max."); break; }
@@ -708,6 +759,7 @@ class LMDriver {
     PackLayout L_;
     std::vector<double> pack_;
     bool speculate_ = true;
+    bool line_search_ = true;
     ExchangeStats xs_;
     std::vector<char> active_, eff_;
     std::vector<char> cam_var_;

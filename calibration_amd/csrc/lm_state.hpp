@@ -23,7 +23,7 @@ struct HipLMState {
     // the packed exchange buffer of a linear solve (lm_core.hpp PackLayout): assembled and all-reduced on the device
     DevBuf<double> pack_dev, sys_tiles, stat_dev;
     PinnedBuf<double> pin_packed;
-    int64_t xs[6] = {0, 0, 0, 0, 0, 0};  // ExchangeStats of the last solve (cba_reproj_solve_stats)
+    int64_t xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ExchangeStats of the last solve (cba_reproj_solve_stats)
     // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
     // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
     // problems (C1: ~25 API calls of 5-10 us per iteration against ~100 us of kernels).  What changes between launches
@@ -61,6 +61,8 @@ inline HipLMState* lm_state(Engine& e) { return reinterpret_cast<HipLMState*>(e.
 // resident_lm.hip: the whole LM in one single-workgroup kernel, for problems too small to fill the chip
 bool resident_lm_eligible(const Engine& e, const cba_options& o);
 void resident_lm_warm(Engine& e);
-void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters = false);
+// false: a step of a bounds-constrained problem needs Ceres' line search (line_search.hpp) — nothing was changed, the caller runs
+// the host-driven iteration instead
+bool resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters = false);
 
 }  // namespace cba

@@ -46,13 +46,13 @@ struct ResidentArgs {
     double *view_L, *view_y, *view_D, *view_gp, *view_scale2, *blk_Z, *view_delta;
     double *Hcc, *Ssch;
     const int8_t *active, *cam_var;
-    int intr_var, target_var, constrained;
+    int intr_var, target_var, constrained, line_search;
     double huber, eps;
     int max_iterations;
     double* out;  // [8]: termination, iterations, successful steps, initial cost, final cost, message id; [8..8+RES_PROF): phase ticks
 };
 
-enum ResidentMsg { MSG_GRADIENT = 0, MSG_MAX_ITER, MSG_MIN_RADIUS, MSG_INVALID_STEPS, MSG_PARAMETER, MSG_FUNCTION };
+enum ResidentMsg { MSG_GRADIENT = 0, MSG_MAX_ITER, MSG_MIN_RADIUS, MSG_INVALID_STEPS, MSG_PARAMETER, MSG_FUNCTION, MSG_LINE_SEARCH };
 static const char* const kResidentMsg[] = {"Gradient tolerance reached.", "Maximum number of iterations reached.",
                                            "Minimum trust region radius reached.",
                                            "Number of consecutive invalid steps more than max.", "Parameter tolerance reached.",
@@ -648,6 +648,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident_lm(const ResidentArgs 
                 double cand = phase_resid_cost<MODEL>(a, 1, sh);
                 tick(8);
                 if (!(fabs(cand) <= 1.7976931348623157e308)) cand = 1.7976931348623157e308;
+                // Bounds-constrained problem and the full step fails the Armijo test: Ceres would now search along the step
+                // (line_search.hpp).  That search lives in the host-driven iteration; this kernel hands the solve back untouched
+                // (the host re-runs it from the start point: such steps are rare, and a problem this size costs a millisecond).
+                if (a.constrained && a.line_search && !(cand <= sh.cost + 1e-4 * (st[2] + st[4]))) { term = CBA_TERM_FAILURE; msg = MSG_LINE_SEARCH; break; }
                 const double step_norm = sqrt(st[0]), x_norm = sqrt(st[1]);
                 if (step_norm <= eps * (x_norm + eps)) { term = CBA_TERM_CONVERGENCE; msg = MSG_PARAMETER; break; }
                 const double cost_change = sh.cost - cand;
@@ -768,7 +772,7 @@ void resident_lm_warm(Engine& e) {
     (void)st;
 }
 
-void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters) {
+bool resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters) {
     const auto t0 = std::chrono::steady_clock::now();
     HipLMState& st = *lm_state(e);
     const Structure& s = st.s;
@@ -784,6 +788,7 @@ void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool k
         void accept() override {}
         void download_private(double*) override {}
         void download_blocks(std::vector<double>&, std::vector<double>&) override {}
+        void line_eval(double, double, bool, const PackLayout&, const AllReduce&, int, double*) override {}
     } nb(e);
     LMDriver drv(s, nb, e.h_intr, e.h_cam, e.h_view, e.h_target, [](double*, int64_t) {}, 1, 0);
     const LMDriver::Masks mk = drv.masks(o);
@@ -801,6 +806,8 @@ void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool k
     ResidentArgs a = resident_args(e, st);
     a.intr_var = mk.intr_var; a.target_var = mk.target_var; a.constrained = mk.constrained;
     a.huber = o.huber_delta; a.eps = o.epsilon; a.max_iterations = o.max_iterations;
+    a.line_search = 1;
+    if (const char* env = std::getenv("CBA_LM_LINE_SEARCH")) a.line_search = std::atoi(env) != 0;
     resident_launch(e, a);
     // results: [out(8) | intr | cam | target | views] through one pinned buffer, one synchronisation
     const size_t n_intr = e.h_intr.size(), n_cam = e.h_cam.size(), n_view = e.h_view.size();
@@ -815,6 +822,14 @@ void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool k
     if (n_view) e.view[0].download(p + 8 + n_intr + n_cam + 7, n_view, e.stream);
     CBA_HIP(hipStreamSynchronize(e.stream));
     e.active = 0;
+    if (static_cast<int>(p[5]) == MSG_LINE_SEARCH) {  // hand the solve to the host-driven iteration: device copy 0 back to the start point
+        if (!e.h_view.empty()) e.view[0].upload(e.h_view.data(), e.h_view.size(), e.stream);
+        e.intr[0].upload(e.h_intr.data(), e.h_intr.size(), e.stream);
+        if (e.chain != CBA_CHAIN_INTRINSIC) e.cam[0].upload(e.h_cam.data(), e.h_cam.size(), e.stream);
+        if (e.chain == CBA_CHAIN_BUNDLE) e.target[0].upload(e.h_target.data(), 7, e.stream);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        return false;
+    }
     if (!keep_parameters) {
         std::memcpy(e.h_intr.data(), p + 8, sizeof(double) * n_intr);
         if (e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(e.h_cam.data(), p + 8 + n_intr, sizeof(double) * n_cam);
@@ -839,6 +854,7 @@ void resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool k
     out->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::snprintf(out->report, sizeof(out->report), "calibba(schur LM, resident kernel): %s iters=%d cost %.6e -> %.6e",
                   kResidentMsg[msg >= 0 && msg < 6 ? msg : 3], out->iterations, out->initial_cost, out->final_cost);
+    return true;
 }
 
 }  // namespace cba

@@ -187,6 +187,38 @@ CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, c
     out4[3] = rr - dDd - 2.0 * ra;
 }
 
+// Line search (line_search.hpp): the private pose of a view at step size a along the step of the last back-substitution,
+// xt = Plus(x, a * delta_p); out2 = { |xt - x|^2, |x|^2 } (zero for a constant view, as in backsub_view_body)
+CBA_HD void scale_step_view_body(bool fixed, double a, const double* x7, const double* delta_p, double* xt7, double* out2) {
+    if (fixed) {
+        for (int i = 0; i < 7; ++i) xt7[i] = x7[i];
+        out2[0] = out2[1] = 0.0;
+        return;
+    }
+    double d[6], xn = 0.0, s2 = 0.0;
+    for (int i = 0; i < 6; ++i) d[i] = a * delta_p[i];
+    quat_plus(x7, d, xt7);
+    for (int i = 0; i < 3; ++i) xt7[4 + i] = x7[4 + i] + d[3 + i];
+    for (int i = 0; i < 7; ++i) { xn += x7[i] * x7[i]; s2 += (xt7[i] - x7[i]) * (xt7[i] - x7[i]); }
+    out2[0] = s2;
+    out2[1] = xn;
+}
+
+// ... and the view's share of the directional derivative there: (sum over the view's blocks of w_b g_b[0..6)) . delta_p
+CBA_HD double view_slope_body(const SchurDims& d, int nb, const int32_t* blks, const double* blk_acc, const double* blk_w, bool fixed,
+                              const double* delta_p) {
+    if (fixed) return 0.0;
+    double s = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const int b = blks[k];
+        const double* g = blk_acc + static_cast<long long>(b) * d.NACC + d.NH;
+        double t = 0.0;
+        for (int i = 0; i < 6; ++i) t += g[i] * delta_p[i];
+        s += blk_w[b] * t;
+    }
+    return s;
+}
+
 // Z of view v at global shared column g, row k (0 if the view has no block on that column's camera)
 CBA_HD double z_entry(const SchurDims& d, const int32_t* view_cam_blk, const double* blk_Z, int v, int g, int k, int nsh) {
     if (g >= nsh) return 0.0;

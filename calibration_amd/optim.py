@@ -405,10 +405,10 @@ class ReprojHandle:
 
     def solve_stats(self) -> dict:
         """What the last host-driven solve exchanged between ranks (cba_reproj_solve_stats)."""
-        a = (C.c_int64 * 6)()
+        a = (C.c_int64 * 8)()
         capi.check(self.lib, self.lib.cba_reproj_solve_stats(self.h, a))
         return dict(zip(("allreduce_calls", "allreduce_doubles", "speculative_steps", "speculation_hits", "speculation_misses",
-                         "rejected_steps"), (int(v) for v in a)))
+                         "rejected_steps", "line_searches", "line_search_evaluations"), (int(v) for v in a)))
 
     def solve(self, opts: CbaOptions) -> CbaSummary:
         s = CbaSummary()

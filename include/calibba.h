@@ -235,10 +235,12 @@ cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
 /* What the last host-driven cba_reproj_solve on this handle exchanged between ranks (one packed
  * sum-all-reduce per linear solve).  A trial point is linearised ahead of the accept decision, so an accepted step whose
  * gain ratio is >= 0.937 (Ceres then grows the radius by its maximum factor 3, which is the radius the elimination was
- * made with) costs exactly ONE collective; stats6 = {all-reduce calls, all-reduced doubles, speculative steps,
+ * made with) costs exactly ONE collective; stats8 = {all-reduce calls, all-reduced doubles, speculative steps,
  * of those accepted with the predicted radius, accepted with another radius (+1 re-elimination and collective),
- * rejected steps}.  All zero after a resident-kernel solve.  CBA_LM_SPECULATE=0 selects the two-exchange sequence. */
-cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats6[6]);
+ * rejected steps, trust-region steps that went through the projected Armijo line search of bounds-constrained problems,
+ * line-search evaluations (one collective each)}.  All zero after a resident-kernel solve.  CBA_LM_SPECULATE=0 selects the
+ * two-exchange sequence, CBA_LM_LINE_SEARCH=0 switches the line search off. */
+cba_status cba_reproj_solve_stats(const cba_reproj* h, int64_t stats8[8]);
 
 /* Covariance in the reference's layout (ceresutils.h:69-126): dense symmetric, AMBIENT block
  * sizes, block order = get_param_blocks() of the stage (intrinsics.cpp:34-50,

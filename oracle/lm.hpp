@@ -15,10 +15,9 @@
 // pins this file are the reference's ground-truth-recovery tests
 // (tests/unit/*_test.cpp tolerances, see tests/test_oracle_kat.py).
 //
-// Known deviation: Ceres runs a projected Armijo line search on every step of
-// a bounds-constrained problem (fx, fy >= 0 make the intrinsics problems
-// "constrained"); here a full step that would fail the Armijo test is simply
-// rejected by the gain-ratio test.  Same minimiser, possibly different path.
+// On bounds-constrained problems (fx, fy >= 0 make every problem with variable
+// intrinsics "constrained") Ceres runs a projected Armijo line search on every
+// trust-region step before it evaluates the candidate: line_search.hpp.
 //
 // This is a *dense* solver (forms the full tangent-space J^T J), usable up to
 // a few thousand tangent dimensions.  It deliberately shares no code with the
@@ -34,6 +33,7 @@
 #include <thread>
 #include <vector>
 
+#include "line_search.hpp"
 #include "models.hpp"
 
 namespace orc {
@@ -74,6 +74,7 @@ struct LMOptions {
     int max_iterations = 1000;  // optimize.h:26
     int verbose = 0;
     int num_threads = 1;
+    int line_search = 1;        // the projected Armijo search of bounds-constrained problems (line_search.hpp); 0 = off (A/B tests)
 };
 
 enum Termination { TERM_CONVERGENCE = 0, TERM_NO_CONVERGENCE = 1, TERM_FAILURE = 2 };
@@ -83,6 +84,8 @@ struct LMSummary {
     int iterations = 0;
     int successful_steps = 0;
     double initial_cost = 0, final_cost = 0;
+    int line_search_steps = 0;        // trust-region steps the line search shortened
+    int line_search_evaluations = 0;  // cost + gradient evaluations spent in line searches
     char message[160] = {0};
 };
 
@@ -399,6 +402,37 @@ class Problem {
                 continue;
             }
             invalid = 0;
+            if (constrained && o.line_search) {
+                // TrustRegionMinimizer::DoLineSearch: search along delta from x with the projected Plus; on success delta is scaled
+                // by the step size found (1 whenever the full step already satisfies the Armijo condition).  model_change keeps the
+                // value of the FULL step, as in Ceres.
+                double dg0 = 0, dinf = 0;
+                for (int i = 0; i < n; ++i) { dg0 += g[i] * delta[i]; dinf = std::max(dinf, std::fabs(delta[i])); }
+                const std::vector<double> dir = delta;
+                auto eval_at = [&](double a, bool want_gradient) {
+                    LsSample sm;
+                    sm.x = a;
+                    std::vector<double> sd(n), xa, Ha, ga;
+                    for (int i = 0; i < n; ++i) sd[i] = a * dir[i];
+                    plus(x, sd, xa);
+                    double ca = 0;
+                    evaluate(xa, o, want_gradient, &ca, want_gradient ? &Ha : nullptr, want_gradient ? &ga : nullptr);
+                    if (!std::isfinite(ca)) return sm;
+                    if (!want_gradient) { sm.value = ca; sm.value_valid = true; return sm; }
+                    sm.value = ca; sm.value_valid = true;
+                    double dgr = 0;
+                    for (int i = 0; i < n; ++i) dgr += dir[i] * ga[i];
+                    if (std::isfinite(dgr)) { sm.gradient = dgr; sm.gradient_valid = true; }
+                    return sm;
+                };
+                int ne = 0;
+                const double a = armijo_search(cost, dg0, dinf, eval_at, &ne);
+                sum->line_search_evaluations += ne;
+                if (a > 0.0 && a != 1.0) {
+                    ++sum->line_search_steps;
+                    for (int i = 0; i < n; ++i) delta[i] *= a;
+                }
+            }
             plus(x, delta, cand);
             double cand_cost = 0;
             evaluate(cand, o, false, &cand_cost, nullptr, nullptr);

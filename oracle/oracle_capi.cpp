@@ -7,6 +7,7 @@
 // the identical buffers to both sides.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -132,6 +133,7 @@ LMOptions to_lm(const cba_options& o, int threads) {
     LMOptions l;
     l.huber_delta = o.huber_delta; l.epsilon = o.epsilon; l.max_iterations = o.max_iterations;
     l.verbose = o.verbose; l.num_threads = threads;
+    if (const char* env = std::getenv("ORC_LINE_SEARCH")) l.line_search = std::atoi(env);
     return l;
 }
 

@@ -243,6 +243,40 @@ struct CpuBackend final : Backend {
         return true;
     }
     void accept_step() override { blk_acc = alt_acc; blk_w = alt_w; view[0] = view[1]; }
+    void line_eval(double a, double hub, bool want_slope, const PackLayout& L, const AllReduce& ar, int rank, double* pack) override {
+        (void)rank;
+        std::fill(pack, pack + L.size, 0.0);
+        for (int v = 0; v < s.n_views; ++v) {
+            double o2[2];
+            scale_step_view_body(fixed[v] != 0, a, &view[0][7 * static_cast<size_t>(v)], &vdelta[6 * static_cast<size_t>(v)],
+                                 &view[1][7 * static_cast<size_t>(v)], o2);
+            pack[L.stats + PackLayout::STEP2] += o2[0];
+            pack[L.stats + PackLayout::XNORM2] += o2[1];
+        }
+        if (want_slope) {
+            const std::vector<double> keep_acc = blk_acc, keep_w = blk_w;
+            std::vector<double> cam_acc;
+            double cost2[2];
+            normal_eq_at(1, hub, cam_acc, cost2);
+            for (int v = 0; v < s.n_views; ++v)
+                pack[L.stats + PackLayout::SLOPE] += view_slope_body(dims, static_cast<int>(s.link_off[v + 1] - s.link_off[v]),
+                                                                      s.link_blk.data() + s.link_off[v], blk_acc.data(), blk_w.data(),
+                                                                      fixed[v] != 0, &vdelta[6 * static_cast<size_t>(v)]);
+            std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
+            pack[L.stats + PackLayout::TRIAL_COST] = cost2[0];
+            blk_acc = keep_acc; blk_w = keep_w;
+        } else {
+            consts(1);
+            double c = 0.0;
+            for (int b = 0; b < s.n_blocks; ++b) {
+                double rho, w;
+                huber(block_s(1, b), hub, &rho, &w);
+                c += 0.5 * rho;
+            }
+            pack[L.stats + PackLayout::TRIAL_COST] = c;
+        }
+        ar(pack, L.size);
+    }
     void download_private(double* vp) override { std::memcpy(vp, view[0].data(), sizeof(double) * view[0].size()); }
     void download_blocks(std::vector<double>& acc, std::vector<double>& w) override { acc = blk_acc; w = blk_w; }
 };
@@ -286,9 +320,10 @@ const char* hm_last_error(void) { return g_err.c_str(); }
 
 // LM solve with the product's host driver + the CPU test backend.  allreduce may be NULL.
 // speculate: 1 / 0 = linearise trial points ahead of the accept decision or not, -1 = the driver's default (CBA_LM_SPECULATE)
-// stats6 (may be NULL) = {all-reduce calls, all-reduced doubles, speculative steps, hits, misses, rejected steps}
+// stats8 (may be NULL) = {all-reduce calls, all-reduced doubles, speculative steps, hits, misses, rejected steps, line searches,
+// line-search evaluations}
 int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
-                       int speculate, cba_summary* out, int64_t* stats6) {
+                       int speculate, cba_summary* out, int64_t* stats8) {
     return guarded([&] {
         Session ss;
         load(*d, ss);
@@ -300,10 +335,11 @@ int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_al
         if (speculate >= 0) drv.set_speculate(speculate != 0);
         drv.solve(*o, out);
         store(*d, ss);
-        if (stats6) {
+        if (stats8) {
             const ExchangeStats& x = drv.exchange_stats();
-            stats6[0] = x.allreduce_calls; stats6[1] = x.allreduce_doubles; stats6[2] = x.speculative_steps;
-            stats6[3] = x.speculation_hits; stats6[4] = x.speculation_misses; stats6[5] = x.rejected_steps;
+            stats8[0] = x.allreduce_calls; stats8[1] = x.allreduce_doubles; stats8[2] = x.speculative_steps;
+            stats8[3] = x.speculation_hits; stats8[4] = x.speculation_misses; stats8[5] = x.rejected_steps;
+            stats8[6] = x.line_searches; stats8[7] = x.line_search_evaluations;
         }
     });
 }

@@ -188,7 +188,7 @@ def test_schur_lm_driver_matches_dense_oracle(oracle, hostmath, kind, model, skw
 def hm_solve_ex(hostmath, flat, o, speculate):
     d = flat.struct()
     s = CbaSummary()
-    xs = (C.c_int64 * 6)()
+    xs = (C.c_int64 * 8)()
     st = hostmath.hm_reproj_solve_ex(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, speculate, C.byref(s), xs)
     assert st == 0, hostmath.hm_last_error()
     return s, [int(v) for v in xs]
@@ -212,13 +212,14 @@ def test_speculative_steps_take_the_same_decisions_as_the_two_exchange_sequence(
     assert (sb.termination, sb.iterations, sb.successful_steps) == (sa.termination, sa.iterations, sa.successful_steps), (sa.report, sb.report)
     assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * max(1.0, sa.final_cost) + 1e-20
     assert helpers.param_diff(a.flat, b.flat) <= (1e-8 if model == 1 else 1e-11)
-    calls, _n, spec, hits, misses, rejected = xb
+    calls, _n, spec, hits, misses, rejected, _ls, ls_evals = xb
     assert xa[2] == 0 and spec >= 1 and hits + misses <= spec
     # plain: every iteration exchanges the trial statistics and then a system (2), plus the initial system
-    assert xa[0] == 1 + 2 * sa.iterations - (1 if sa.success and sa.iterations > 0 and "tolerance" in sa.report.decode() and "Gradient" not in sa.report.decode() else 0)
+    assert xa[0] == xa[7] + 1 + 2 * sa.iterations - (1 if sa.success and sa.iterations > 0 and "tolerance" in sa.report.decode() and "Gradient" not in sa.report.decode() else 0)
     # speculative: one exchange per trial point; one more only for a rejected step, a radius miss, or a step accepted after a plain trial
-    assert calls == 1 + sb.iterations + misses + rejected + (sb.successful_steps - hits - misses)
-    assert calls < xa[0]
+    # ... and one per line-search sample (bounds-constrained problems, steps that fail the Armijo test at step size 1)
+    assert calls == 1 + sb.iterations + misses + rejected + (sb.successful_steps - hits - misses) + ls_evals
+    assert calls < xa[0] and xa[7] == ls_evals
 
 
 @pytest.mark.parametrize("seed", [3, 5])

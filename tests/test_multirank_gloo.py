@@ -64,7 +64,7 @@ def _worker(rank, world, port, kind, okw, outdir):
     d = flat.struct()
     s = CbaSummary()
     o = helpers.options(epsilon=1e-12, **okw)
-    xs = (C.c_int64 * 6)()
+    xs = (C.c_int64 * 8)()
     st = hm.hm_reproj_solve_ex(C.byref(d), C.byref(o), cb, None, world, rank, -1, C.byref(s), xs)
     assert st == 0, hm.hm_last_error()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), intr=flat.intr, cam=flat.cam_pose if flat.cam_pose is not None else np.zeros(0),
@@ -106,12 +106,12 @@ def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw):
         # ONE packed all-reduce per LM step.  Every trial point is one exchange (speculative steps carry
         # the next system with their statistics); beyond those: the initial system, one re-elimination per rejected step and per
         # accepted step whose radius was not the predicted one, one new system per step accepted after a plain (cost-only) trial.
-        calls, _doubles, spec, hits, misses, rejected = (int(v) for v in r["xs"])
+        calls, _doubles, spec, hits, misses, rejected, _ls, ls_evals = (int(v) for v in r["xs"])
         iters, accepted = int(r["iters"]), int(r["accepted"])
         assert calls == int(r["ncalls"]) and spec >= 1 and hits >= 1 and hits + misses <= spec
         accepted_plain = accepted - hits - misses
-        assert calls == 1 + iters + misses + rejected + accepted_plain
-        assert calls <= iters + 1 + misses + 2 * rejected  # one collective per step, plus one per rejection / radius miss
+        assert calls == 1 + iters + misses + rejected + accepted_plain + ls_evals
+        assert calls <= iters + 1 + misses + 2 * rejected + 2 * ls_evals  # one collective per step, plus one per rejection / radius miss / line-search sample
     # replicated blocks are bit-identical across ranks (same all-reduced sums, same host arithmetic)
     assert np.array_equal(res[0]["intr"], res[1]["intr"]) and np.array_equal(res[0]["cam"], res[1]["cam"])
     if ref.view_pose is not None:
