@@ -118,17 +118,17 @@ def main():
                 "kernel": "k_eval<INTRINSIC,PINHOLE_BC>", "kernel_ms": ms_kernel, "bytes_per_eval": bytes_per_obs}
 
     # ---- Mode B (per-block normal equations, the kernel that sets the LM wall clock): fp64-issue bound ----------------
-    # FLOPs counted from the ISA of the two launches' hot loops (tools/isa_mix.py on the shipped kernels, FMA = 2, mul / add = 1;
-    # profiles/r02_modeb_isa_mix.txt): per observation and launch 159 FMA + 81 mul/add = 399 FLOP ISSUED, of which 113 FMA are
-    # the launch's share of the 225 accumulate operations of [H | g | s] and the rest is the residual / Jacobian row evaluation,
-    # which BOTH launches repeat.  USEFUL work = 225 accumulate FMAs + one row evaluation = 450 + 173 FLOP.
+    # FLOPs counted from the ISA of the shipped kernel's hot loop (tools/isa_mix.py, FMA = 2, mul / add = 1;
+    # profiles/r02_modeb_isa_mix.txt): one workgroup of two wavefronts per tile, each accumulating its half of the 225 FMAs of
+    # [H | g | s] for every observation and evaluating the residual / Jacobian rows of every second 64-observation chunk (the other
+    # chunk's rows arrive through LDS): 257 FMA + 94 mul/add per wavefront and pair of chunks = 608 FLOP per observation, all of
+    # it useful work (round 1 evaluated the rows once per launch: 786 FLOP issued for the same 608).
     ms_b = h.normal_eq_timed(2, 10)
-    flop_issued, flop_useful = 2 * 399, 450 + 173
-    mode_b = {"kernel": "k_normal_eq<INTRINSIC,PINHOLE_BC> x2 + k_tile_sum", "ms_per_pass": ms_b, "bound": "fp64 vector issue",
-              "flop_per_obs_issued": flop_issued, "flop_per_obs_useful": flop_useful,
-              "issued_TFLOPs": flop_issued * n_obs / (ms_b * 1e-3) / 1e12, "useful_TFLOPs": flop_useful * n_obs / (ms_b * 1e-3) / 1e12,
-              "peak_TFLOPs": 78.6, "frac_issued": flop_issued * n_obs / (ms_b * 1e-3) / 78.6e12,
-              "frac_useful": flop_useful * n_obs / (ms_b * 1e-3) / 78.6e12, "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
+    flop_per_obs = 608
+    mode_b = {"kernel": "k_ne_shared<DirectForm<INTRINSIC,PINHOLE_BC,2 parts>> + k_tile_sum", "ms_per_pass": ms_b, "bound": "fp64 vector issue",
+              "flop_per_obs": flop_per_obs, "valu_instructions_per_obs": 382, "achieved_TFLOPs": flop_per_obs * n_obs / (ms_b * 1e-3) / 1e12,
+              "peak_TFLOPs": 78.6, "frac": flop_per_obs * n_obs / (ms_b * 1e-3) / 78.6e12,
+              "issue_slots_frac_at_2GHz": 382 * 4 * (n_obs / 64 / 1024) / (ms_b * 1e-3 * 2.0e9), "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path

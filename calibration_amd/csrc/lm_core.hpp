@@ -261,7 +261,7 @@ class LMDriver {
                 if (valid) {
                     shared_plus(delta, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
                     be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
-                    const bool expect_convergence = rel_prev > 0.0 && rel_last > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) <= eps;
+                    const bool expect_convergence = rel_prev > 0.0 && rel_last > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) <= 4.0 * eps;
                     if (speculate_ && !plain_next && !expect_convergence)
                         speculated = be_.sys_step(delta.data(), huber, radius_spec, constrained_, L_, ar_, rank_, pack_.data());
                     if (speculated) {  // statistics and the next system arrived in the same exchange

@@ -111,7 +111,9 @@ def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw):
         assert calls == int(r["ncalls"]) and spec >= 1 and hits >= 1 and hits + misses <= spec
         accepted_plain = accepted - hits - misses
         assert calls == 1 + iters + misses + rejected + accepted_plain + ls_evals
-        assert calls <= iters + 1 + misses + 2 * rejected + 2 * ls_evals  # one collective per step, plus one per rejection / radius miss / line-search sample
+        # one collective per step, plus one per rejection / radius miss / line-search sample / step accepted after a plain trial (a step
+        # evaluated the cheap way because it followed a rejection or was expected to end the solve: at most a few per solve)
+        assert calls <= iters + 1 + misses + 2 * rejected + 2 * ls_evals + accepted_plain and accepted_plain <= 2 + rejected
     # replicated blocks are bit-identical across ranks (same all-reduced sums, same host arithmetic)
     assert np.array_equal(res[0]["intr"], res[1]["intr"]) and np.array_equal(res[0]["cam"], res[1]["cam"])
     if ref.view_pose is not None:

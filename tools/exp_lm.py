@@ -31,7 +31,7 @@ for w in which:
         for rep in range(3):
             h.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
             t = time.perf_counter()
-            s = h.solve(helpers.options(compute_covariance=0))
+            s = h.solve(helpers.options(compute_covariance=0, verbose=int(os.environ.get('EXP_VERBOSE', '0')) if rep == 0 else 0))
             walls.append(time.perf_counter() - t)
         print(json.dumps({"shape": w, "n_obs": int(f.n_obs), "lm_wall_ms": [round(x * 1e3, 3) for x in walls], "iterations": int(s.iterations),
                           "accepted": int(s.successful_steps), "speculate": os.environ.get("CBA_LM_SPECULATE", "1"), "stats": h.solve_stats(),

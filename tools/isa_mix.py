@@ -33,8 +33,8 @@ loops.sort(reverse=True)
 def hist(sub):
     h = collections.Counter(mn for _, mn, _ in sub)
     f64 = {k: v for k, v in h.items() if k.endswith("_f64") or "f64" in k}
-    fma = sum(v for k, v in h.items() if k in ("v_fma_f64", "v_fmac_f64", "v_pk_fma_f32", "v_fma_f32", "v_fmac_f32"))
-    muladd = sum(v for k, v in h.items() if k in ("v_mul_f64", "v_add_f64", "v_mul_f32", "v_add_f32", "v_sub_f32"))
+    fma = sum(v for k, v in h.items() if k.split("_e")[0] in ("v_fma_f64", "v_fmac_f64"))
+    muladd = sum(v for k, v in h.items() if k.split("_e")[0] in ("v_mul_f64", "v_add_f64"))
     valu = sum(v for k, v in h.items() if k.startswith("v_"))
     return h, f64, fma, muladd, valu
 
