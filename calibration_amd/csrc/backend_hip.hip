@@ -931,8 +931,8 @@ void warm_lm(Engine& e) {
     {   // the cost is per process and device (code objects, kernel set-up), not per handle: pay it once per kernel family
         static std::mutex mu;
         static std::set<uint32_t> warmed;
-        const uint32_t key = (static_cast<uint32_t>(e.device) << 8) | (resident ? 0x80u : 0u) | (static_cast<uint32_t>(e.chain) << 2) |
-                             static_cast<uint32_t>(e.model);
+        const uint32_t key = (static_cast<uint32_t>(e.device) << 8) | (resident ? 0x80u : 0u) | (e.scalar ? 0x40u : 0u) |
+                             (static_cast<uint32_t>(e.chain) << 2) | static_cast<uint32_t>(e.model);
         std::lock_guard<std::mutex> lock(mu);
         if (!warmed.insert(key).second) return;
     }

@@ -640,6 +640,7 @@ cba_status cba_reproj_set_scalar(cba_reproj* h, int32_t scalar) {
         if (scalar) ensure_f32_buffers(e);
         e.scalar = scalar;
         e.eval_done = 0;
+        if (scalar) warm_lm(e);  // the fp32 kernel family is a code object of its own: set it up here, not inside the first fp32 solve
     });
 }
 

@@ -451,3 +451,14 @@ def weak_direction_report(orc, fa, fb, fixed=(4,)) -> dict:
     c = V.T @ ds
     return dict(kappa=float(w[-1] / w[0]), rayleigh_over_lmin=float(ds @ Hs @ ds / (ds @ ds) / w[0]) if ds @ ds > 0 else 0.0,
                 weak3_share=float((c[:3] ** 2).sum() / (c ** 2).sum()) if ds @ ds > 0 else 1.0)
+
+
+def rough_start_scene(kind, model, seed):
+    """A scene whose start point is far enough from the optimum (focal lengths 20 % short, no distortion, 0.5 px noise) that some
+    trust-region steps fail the Armijo test: bounds-constrained problems then go through Ceres' projected line search."""
+    from calibration_amd import synth
+
+    sc = synth.scene_intrinsics(6, model=model, noise_px=0.5, seed=seed) if kind == "intr" else synth.scene_extrinsics(4, 2, model=model, noise_px=0.5, seed=seed)
+    sc.flat.intr[:, 5:10] = 0.0
+    sc.flat.intr[:, 0:2] *= 0.8
+    return sc

@@ -177,6 +177,25 @@ def test_scheimpflug_parity_gap_lies_in_the_flat_valley(gpu_lib, oracle, seed):
         assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, (rep, gap)
 
 
+@pytest.mark.parametrize("kind,model,seed", [("intr", 0, 7), ("ext", 0, 9), ("intr", 0, 19), ("ext", 0, 23), ("intr", 0, 4)])
+def test_projected_line_search_on_gpu_matches_the_oracle(gpu_lib, oracle, kind, model, seed):
+    """Ceres' projected Armijo line search (bounds-constrained problems) through the HIP engine: from a rough start
+    some steps fail the Armijo test at step size 1; the engine searches them (`Backend::line_eval`: k_scale_step, Mode R or Mode B +
+    k_view_slope per sample) exactly where the oracle does.  With the resident kernel forced, the kernel hands the solve to the
+    host-driven iteration (same result)."""
+    a, b = helpers.rough_start_scene(kind, model, seed), helpers.rough_start_scene(kind, model, seed)
+    o = options(epsilon=1e-10)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+        xs = h.solve_stats()
+    assert xs["line_searches"] >= 1 and xs["line_search_evaluations"] >= xs["line_searches"], xs
+    assert b"resident" not in bytes(sb.report)
+    assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 2, (sa.report, sb.report)
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-7
+
+
 def test_covariance_matches_oracle(gpu_lib, oracle):
     for mk, okw in ((lambda: synth.scene_intrinsics(6, noise_px=0.2), {}),
                     (lambda: synth.scene_extrinsics(4, 2, noise_px=0.2), {}),

