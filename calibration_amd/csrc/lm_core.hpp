@@ -320,7 +320,11 @@ class LMDriver {
                         int evals = 0;
                         double a = armijo_line_search(cost_, slope0, dmax, sample, &evals);
                         xs_.line_search_evaluations += evals;
-                        if (!(a > 0.0)) { a = 1.0; (void)sample(1.0, false); }  // search failed: the full step, re-established on the device
+                        if (!(a > 0.0)) {  // search failed: the full step, re-established on the device (one more sample)
+                            a = 1.0;
+                            (void)sample(1.0, false);
+                            ++xs_.line_search_evaluations;
+                        }
                         for (int i = 0; i < n; ++i) delta[i] = a * full[i];
                         st.cost = pack_[L_.stats + PackLayout::TRIAL_COST];
                         st.step2 = pack_[L_.stats + PackLayout::STEP2];

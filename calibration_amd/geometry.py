@@ -68,6 +68,61 @@ def pose_to_matrix(p) -> np.ndarray:
     return out
 
 
+def poses_from_matrices(Ts) -> np.ndarray:
+    """pose_from_matrix for a batch: (n, 4, 4) -> (n, 7), the same branches (Eigen's matrix -> quaternion) evaluated with masks —
+    element for element what the scalar routine returns (the batched solvers' mirrors convert thousands of poses per call)."""
+    m = np.asarray(Ts, dtype=np.float64).reshape(-1, 4, 4)
+    n = m.shape[0]
+    q = np.zeros((n, 4))
+    d = np.stack([m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]], axis=1)
+    tr = d[:, 0] + d[:, 1] + d[:, 2]
+    pos = tr > 0
+    if pos.any():
+        t = np.sqrt(tr[pos] + 1.0)
+        q[pos, 0] = 0.5 * t
+        t = 0.5 / t
+        mp = m[pos]
+        q[pos, 1] = (mp[:, 2, 1] - mp[:, 1, 2]) * t
+        q[pos, 2] = (mp[:, 0, 2] - mp[:, 2, 0]) * t
+        q[pos, 3] = (mp[:, 1, 0] - mp[:, 0, 1]) * t
+    neg = ~pos
+    if neg.any():
+        i = np.zeros(n, dtype=np.int64)
+        i[d[:, 1] > d[:, 0]] = 1
+        i[d[:, 2] > d[np.arange(n), i]] = 2
+        for ii in range(3):
+            sel = neg & (i == ii)
+            if not sel.any():
+                continue
+            j, k = (ii + 1) % 3, (ii + 2) % 3
+            ms = m[sel]
+            t = np.sqrt(ms[:, ii, ii] - ms[:, j, j] - ms[:, k, k] + 1.0)
+            q[sel, 1 + ii] = 0.5 * t
+            t = 0.5 / t
+            q[sel, 0] = (ms[:, k, j] - ms[:, j, k]) * t
+            q[sel, 1 + j] = (ms[:, j, ii] + ms[:, ii, j]) * t
+            q[sel, 1 + k] = (ms[:, k, ii] + ms[:, ii, k]) * t
+    return np.concatenate([q, m[:, :3, 3]], axis=1)
+
+
+def poses_to_matrices(P) -> np.ndarray:
+    """pose_to_matrix for a batch: (n, 7) -> (n, 4, 4) (quaternions normalised, as restore_pose does)."""
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 7)
+    q = P[:, :4] / np.linalg.norm(P[:, :4], axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    out = np.zeros((P.shape[0], 4, 4))
+    out[:, 0, 0] = 1 - (tyy + tzz); out[:, 0, 1] = txy - twz; out[:, 0, 2] = txz + twy
+    out[:, 1, 0] = txy + twz; out[:, 1, 1] = 1 - (txx + tzz); out[:, 1, 2] = tyz - twx
+    out[:, 2, 0] = txz - twy; out[:, 2, 1] = tyz + twx; out[:, 2, 2] = 1 - (txx + tyy)
+    out[:, :3, 3] = P[:, 4:]
+    out[:, 3, 3] = 1.0
+    return out
+
+
 def quat_plus(q, d) -> np.ndarray:
     """ceres::QuaternionManifold::Plus: q_d (x) q, q_d = [cos|d|, sin|d|/|d| d]."""
     q = np.asarray(q, dtype=np.float64)

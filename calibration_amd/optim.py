@@ -145,7 +145,7 @@ class HandeyeResult:  # handeye.h:16-19
 
 
 # ---- pose helpers (observationutils.h:43-62): host logic, see geometry.py -----------------------
-from .geometry import pose_from_matrix, pose_to_matrix  # noqa: E402
+from .geometry import pose_from_matrix, pose_to_matrix, poses_from_matrices, poses_to_matrices  # noqa: E402
 
 
 def camera_model_of(cam: np.ndarray) -> int:
@@ -596,7 +596,7 @@ def optimize_planar_pose_batch(views, intrinsics, init_poses, opts: Optional[Pla
     allv = np.concatenate(vs, axis=0) if nv else np.zeros((0, 4))
     X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
     K = np.ascontiguousarray(np.asarray(intrinsics, dtype=np.float64).reshape(5))
-    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_poses])) if nv else np.zeros((0, 7))
+    poses = np.ascontiguousarray(poses_from_matrices(np.asarray(init_poses, dtype=np.float64))) if nv else np.zeros((0, 7))
     m = int(opts.num_radial) + 2
     summ = (CbaSummary * max(nv, 1))()
     dist = np.zeros((max(nv, 1), m))
@@ -607,9 +607,10 @@ def optimize_planar_pose_batch(views, intrinsics, init_poses, opts: Optional[Pla
                                                        dptr(poses), C.byref(copts), summ, dptr(dist), dptr(rms),
                                                        dptr(cov) if opts.core.compute_covariance else dptr(None)))
     out = []
+    mats = poses_to_matrices(poses) if nv else np.zeros((0, 4, 4))
+    has_cov = np.any(cov != 0.0, axis=1) if opts.core.compute_covariance else np.zeros(max(nv, 1), dtype=bool)
     for i in range(nv):
-        c = cov[i].reshape(6, 6).copy() if opts.core.compute_covariance and np.any(cov[i]) else None
-        out.append(PlanarPoseResult(result_core(summ[i], c), pose_to_matrix(poses[i]), dist[i].copy(), float(rms[i])))
+        out.append(PlanarPoseResult(result_core(summ[i], cov[i].reshape(6, 6).copy() if has_cov[i] else None), mats[i], dist[i].copy(), float(rms[i])))
     return out
 
 

@@ -907,3 +907,22 @@ def test_masks_handed_to_the_resident_solver(hostmath, kind, okw, expect):
     assert [int(x) for x in flags] == [expect["intr_var"], expect["target_var"], expect["constrained"]]
     if kind == "ext":
         assert cam_var[0] == 0  # camera 0 is the gauge
+
+
+def test_batched_pose_conversions_equal_the_scalar_ones():
+    """geometry.poses_from_matrices / poses_to_matrices (used by the batched solvers' mirrors) against pose_from_matrix /
+    pose_to_matrix element for element, over all four branches of Eigen's matrix -> quaternion conversion."""
+    from calibration_amd.geometry import poses_from_matrices, poses_to_matrices
+
+    rng = np.random.default_rng(3)
+    Ts = []
+    for k in range(400):
+        ax = rng.normal(size=3)
+        ang = rng.uniform(0, np.pi) if k % 3 else np.pi - rng.uniform(0, 1e-3)  # near 180 degrees: the trace <= 0 branches
+        Ts.append(make_pose(rng.normal(size=3), ax / np.linalg.norm(ax), ang))
+    P = poses_from_matrices(np.asarray(Ts))
+    assert np.array_equal(P, np.stack([pose_from_matrix(T) for T in Ts]))
+    assert (np.trace(np.asarray(Ts)[:, :3, :3], axis1=1, axis2=2) <= 0).sum() > 50
+    M = poses_to_matrices(P * rng.uniform(0.5, 2.0, size=(len(Ts), 1)) * np.r_[1, 1, 1, 1, 0, 0, 0] + P * np.r_[0, 0, 0, 0, 1, 1, 1])
+    assert np.abs(M - np.asarray(Ts)).max() < 1e-12
+    assert np.abs(poses_to_matrices(P) - np.stack([pose_to_matrix(p) for p in P])).max() <= 1e-14  # (the norm is summed in another order)
