@@ -128,7 +128,7 @@ def main():
     mode_b = {"kernel": "k_ne_shared<DirectForm<INTRINSIC,PINHOLE_BC,2 parts>> + k_tile_sum", "ms_per_pass": ms_b, "bound": "fp64 vector issue",
               "flop_per_obs": flop_per_obs, "valu_instructions_per_obs": 382, "achieved_TFLOPs": flop_per_obs * n_obs / (ms_b * 1e-3) / 1e12,
               "peak_TFLOPs": 78.6, "frac": flop_per_obs * n_obs / (ms_b * 1e-3) / 78.6e12,
-              "issue_slots_frac_at_2GHz": 382 * 4 * (n_obs / 64 / 1024) / (ms_b * 1e-3 * 2.0e9), "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
+              "issue_slots_frac_at_2p4GHz": 382 * 4 * (n_obs / 64 / 1024) / (ms_b * 1e-3 * 2.4e9), "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path

@@ -46,7 +46,7 @@ for i in range(n_cases):
     T = synth.random_view_poses(1, rng, dist=float(rng.uniform(0.5, 2.0)), max_tilt_deg=35.0, jitter=0.1)[0]
     views.append(synth.render_view(cam, T, synth.make_target_grid(rows, cols, 0.05), float(rng.choice([0.0, 0.2])), rng, cull=False))
     inits.append(synth.perturb_pose(T, rng, rot_deg=2.0, trans=0.01))
-bad = 0
+bad, bad_pp = 0, []
 for nr in (0, 1, 2, 3):
     res = optim.optimize_planar_pose_batch(views, cam[:5], inits, optim.PlanarPoseOptions(num_radial=nr))
     o = helpers.options()
@@ -62,7 +62,10 @@ for nr in (0, 1, 2, 3):
         ok = bool(s.success) == r.core.success and abs(s.iterations - r.core.iterations) <= 2 and np.abs(p - pr).max() <= 1e-6 and \
             abs(rms.value - r.reprojection_error) <= 1e-8
         bad += not ok
-out["planar_pose"] = dict(cases=4 * n_cases, disagreements=int(bad))
+        if not ok:
+            bad_pp.append(dict(nr=nr, n_points=len(view), success=[bool(s.success), r.core.success], iters=[int(s.iterations), int(r.core.iterations)],
+                               pose_diff=float(np.abs(p - pr).max()), rms=[rms.value, r.reprojection_error]))
+out["planar_pose"] = dict(cases=4 * n_cases, disagreements=int(bad), bad=bad_pp[:8])
 
 # ---- semi-DLT: 4..6 views, random options ----------------------------------------------------------------------------------------
 bad, worst = 0, 0.0
