@@ -20,6 +20,7 @@
 #include "lm_core.hpp"
 #include "lm_state.hpp"
 #include "schur_math.hpp"
+#include "wave_reduce.hpp"
 
 namespace cba {
 
@@ -166,6 +167,86 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
                                     L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
                                     gp + 6 * static_cast<int64_t>(v), blk_Z, &gm);
     gmax[v] = ok ? gm : -1.0;
+}
+
+// The same elimination with ONE WAVEFRONT per view (4 views per workgroup).  One thread per view is a ~100 us latency chain however
+// few views there are (8-camera rig: 8 blocks x 16 shared columns of forward substitutions per view, 107 us for 500 views and 84 us
+// for 4000): here every lane runs the short factor part redundantly and the lanes split the (block, column) pairs of Z.  Same
+// operations per value as the serial body: bit-identical results.
+__global__ __launch_bounds__(256) void k_schur_view_wave(SchurDims d, int n_views, const int64_t* __restrict__ link_off,
+                                                         const int32_t* __restrict__ link_blk, const double* __restrict__ blk_acc,
+                                                         const double* __restrict__ blk_w, const int32_t* __restrict__ fixed,
+                                                         const double* __restrict__ lmp, int constrained, const double* __restrict__ view,
+                                                         double* __restrict__ scale2, double* __restrict__ L, double* __restrict__ y,
+                                                         double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
+                                                         double* __restrict__ gmax) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n_views) return;
+    const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
+    const int32_t* blks = link_blk + link_off[v];
+    const int n_pairs = nb * d.PSH;
+    if (fixed[v] != 0) {
+        if (lane == 0) {
+            double* Lv = L + 36 * static_cast<int64_t>(v);
+            for (int i = 0; i < 36; ++i) Lv[i] = (i % 7 == 0) ? 1.0 : 0.0;
+            for (int i = 0; i < 6; ++i) {
+                y[6 * static_cast<int64_t>(v) + i] = 0.0; D[6 * static_cast<int64_t>(v) + i] = 0.0; gp[6 * static_cast<int64_t>(v) + i] = 0.0;
+                if (lmp[1] != 0.0) scale2[6 * static_cast<int64_t>(v) + i] = 1.0;
+            }
+            gmax[v] = 0.0;
+        }
+        for (int p = lane; p < n_pairs; p += 64) {
+            const int k = p / d.PSH, c = p - k * d.PSH;
+            double* Z = blk_Z + static_cast<int64_t>(blks[k]) * 6 * d.PSH;
+            for (int i = 0; i < 6; ++i) Z[i * d.PSH + c] = 0.0;
+        }
+        return;
+    }
+    double F[36], rd[6], gm = 0.0;
+    const bool ok = schur_view_factor(d, nb, blks, blk_acc, blk_w, lmp[0], lmp[1] != 0.0, constrained != 0, view + 7 * static_cast<int64_t>(v),
+                                      scale2 + 6 * static_cast<int64_t>(v), L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v),
+                                      D + 6 * static_cast<int64_t>(v), gp + 6 * static_cast<int64_t>(v), &gm, lane == 0, F, rd);
+    if (lane == 0) gmax[v] = ok ? gm : -1.0;
+    if (!ok) return;
+    for (int p = lane; p < n_pairs; p += 64) {
+        const int k = p / d.PSH, c = p - k * d.PSH;
+        const int b = blks[k];
+        schur_view_zcol(d, F, rd, blk_w[b], blk_acc + static_cast<int64_t>(b) * d.NACC, c, blk_Z + static_cast<int64_t>(b) * 6 * d.PSH);
+    }
+}
+
+// ... and the back-substitution: the lanes split a = Z d_c over the (block, column) pairs (fixed assignment, fixed-order DPP
+// wave sums: deterministic; rounding differs from the serial body's summation order), lane 63 finishes
+__global__ __launch_bounds__(256) void k_backsub_wave(SchurDims d, int n_views, const int64_t* __restrict__ link_off,
+                                                      const int32_t* __restrict__ link_blk, const int32_t* __restrict__ blk_cam,
+                                                      const double* __restrict__ blk_Z, const double* __restrict__ delta_sh,
+                                                      const int32_t* __restrict__ fixed, const double* __restrict__ L, const double* __restrict__ y,
+                                                      const double* __restrict__ D, const double* __restrict__ gp, const double* __restrict__ x,
+                                                      double* __restrict__ delta_p, double* __restrict__ xt, double* __restrict__ stats) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n_views) return;
+    const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
+    const int32_t* blks = link_blk + link_off[v];
+    const bool fx = fixed[v] != 0;
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!fx) {
+        const int n_pairs = nb * d.PSH;
+        for (int p = lane; p < n_pairs; p += 64) {
+            const int k = p / d.PSH, c = p - k * d.PSH;
+            const int b = blks[k];
+            const double dc = delta_sh[blk_cam[b] * d.PC + c];
+            const double* Z = blk_Z + static_cast<int64_t>(b) * 6 * d.PSH + c;
+            for (int i = 0; i < 6; ++i) a[i] += Z[i * d.PSH] * dc;
+        }
+        for (int i = 0; i < 6; ++i) a[i] = wave_sum63(a[i]);  // total in lane 63
+    }
+    if (lane == 63) {
+        double o4[4];
+        backsub_view_finish(fx, a, L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
+                            gp + 6 * static_cast<int64_t>(v), x + 7 * static_cast<int64_t>(v), delta_p + 6 * static_cast<int64_t>(v),
+                            xt + 7 * static_cast<int64_t>(v), o4);
+        for (int k = 0; k < 4; ++k) stats[4 * static_cast<int64_t>(v) + k] = o4[k];
+    }
 }
 
 // g_schur partial of one view chunk: out[g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k] (fixed order); run by the (chunk, pair 0)
@@ -500,10 +581,16 @@ struct HipBackend final : Backend {
     void enqueue_schur(bool constrained, int which = 0, double* tiles_out = nullptr) {
         const Structure& s = st.s;
         const int n = s.nsh;
-        hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                           st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
-                           e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
-                           st.view_gmax.p);
+        if (st.schur_wave)
+            hipLaunchKernelGGL(k_schur_view_wave, dim3(nblk(s.n_views, 4)), dim3(256), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
+                               e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
+                               st.view_gmax.p);
+        else
+            hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
+                               e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
+                               st.view_gmax.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
         if (n >= 64 && st.syrk_mfma)
             hipLaunchKernelGGL(k_schur_syrk_mfma, dim3(st.n_vchunks, st.n_pairs), dim3(256), 0, e.stream, st.dims, s.n_views, n, st.n_tiles,
@@ -649,7 +736,7 @@ struct HipBackend final : Backend {
         std::memcpy(st.pin_pack[1].p + e.pk_delta, delta_sh, sizeof(double) * s.nsh);
         e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta + static_cast<size_t>(s.nsh), e.stream);  // trial blocks + step
         if (q2) {  // statistics of the step from the CURRENT factors, trial poses into copy 1
-            hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+            hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)), st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
                                e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
             hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
@@ -737,7 +824,7 @@ struct HipBackend final : Backend {
         run_stage(st.g_trial, huber, false, [&] {
             e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta + static_cast<size_t>(s.nsh), e.stream);  // trial blocks + step
             if (s.n_views > 0) {
-                hipLaunchKernelGGL(k_backsub, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
+                hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)), st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                    st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
                                    e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
                 hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
@@ -831,6 +918,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
         warm_reproj_kernels();
     }
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
+    if (const char* env = std::getenv("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);
         st->graphs_ok = v != 0;

@@ -75,6 +75,68 @@ CBA_HD void bwd6(const double* L, double* b) {  // b <- L^-T b
 // Private-view elimination.  Outputs: L (36, lower), y (6), D (6), gp (6), scale2 (6, written when
 // init_scale), Z of every block of the view ([6][PSH] at blk_Z + b*6*PSH), *gmax = the view's
 // contribution to Ceres' gradient max-norm.  Returns false if the damped H_pp is not PD.
+// The elimination of one view in two pieces, so that a wavefront can share it (backend_hip.hip k_schur_view_wave: every lane
+// runs the factor part redundantly — it is a latency chain, not work — and the lanes split the Z columns); the serial form below
+// is the same pieces in sequence, so both give bit-identical results.
+//   schur_view_factor: H_pp, g_p, scale, damping, Cholesky, y.  F (36) = the factor, rd (6) = reciprocal pivots, in the caller's
+//   registers; L / y / D / gp / scale2 / gmax are written only when `store` (one lane).  Returns false if not positive definite.
+CBA_HD bool schur_view_factor(const SchurDims& d, int nb, const int32_t* blks, const double* blk_acc, const double* blk_w,
+                              double radius, bool init_scale, bool constrained, const double* xview7, double* scale2, double* L,
+                              double* y, double* D, double* gp, double* gmax, bool store, double* F, double* rd) {
+    double gl[6], sc2[6];
+    for (int i = 0; i < 36; ++i) F[i] = 0.0;
+    for (int i = 0; i < 6; ++i) gl[i] = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const int b = blks[k];
+        const double w = blk_w[b];
+        const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
+        for (int i = 0; i < 6; ++i) {
+            for (int j = i; j < 6; ++j) F[i * 6 + j] += w * acc[hidx(d.PL, i, j)];
+            gl[i] += w * acc[d.NH + i];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < i; ++j) F[i * 6 + j] = F[j * 6 + i];
+    for (int i = 0; i < 6; ++i) {
+        if (init_scale) { const double s = 1.0 / (1.0 + sqrt(F[i * 6 + i])); sc2[i] = s * s; }
+        else sc2[i] = scale2[i];
+    }
+    // gradient max-norm contribution (trust_region_minimizer.cc: inf-norm of the tangent gradient,
+    // or of Plus(x, -g) - x when the problem is bounds-constrained)
+    double gm = 0.0;
+    if (!constrained) {
+        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
+    } else {
+        const double ng[3] = {-gl[0], -gl[1], -gl[2]};
+        double qn[4];
+        quat_plus(xview7, ng, qn);
+        for (int i = 0; i < 4; ++i) gm = fmax(gm, fabs(qn[i] - xview7[i]));
+        for (int i = 3; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
+    }
+    double Dl[6];
+    for (int i = 0; i < 6; ++i) {
+        Dl[i] = lm_diag(F[i * 6 + i], sc2[i], radius);
+        F[i * 6 + i] += Dl[i];
+    }
+    const bool ok = chol6(F);  // F now holds the factor: every substitution reads this local copy, not L
+    double yl[6];
+    for (int i = 0; i < 6; ++i) { yl[i] = gl[i]; rd[i] = 1.0 / F[i * 6 + i]; }
+    if (ok) fwd6r(F, rd, yl);
+    if (store) {
+        *gmax = gm;
+        for (int i = 0; i < 36; ++i) L[i] = F[i];
+        for (int i = 0; i < 6; ++i) { gp[i] = gl[i]; D[i] = Dl[i]; y[i] = yl[i]; if (init_scale) scale2[i] = sc2[i]; }
+    }
+    return ok;
+}
+// column c of Z_b = L^-1 (w_b H_b[A, shared column c])
+CBA_HD void schur_view_zcol(const SchurDims& d, const double* F, const double* rd, double w, const double* acc, int c, double* Z) {
+    double e[6];
+    for (int i = 0; i < 6; ++i) e[i] = w * acc[hidx(d.PL, i, 6 + c)];
+    fwd6r(F, rd, e);
+    for (int i = 0; i < 6; ++i) Z[i * d.PSH + c] = e[i];
+}
+
 CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, const double* blk_acc, const double* blk_w,
                             bool fixed, double radius, bool init_scale, bool constrained, const double* xview7,
                             double* scale2, double* L, double* y, double* D, double* gp, double* blk_Z, double* gmax) {
@@ -88,58 +150,13 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
         *gmax = 0.0;
         return true;
     }
-    double H[36], gl[6];
-    for (int i = 0; i < 36; ++i) H[i] = 0.0;
-    for (int i = 0; i < 6; ++i) gl[i] = 0.0;
+    double F[36], rd[6];
+    if (!schur_view_factor(d, nb, blks, blk_acc, blk_w, radius, init_scale, constrained, xview7, scale2, L, y, D, gp, gmax, true, F, rd))
+        return false;
     for (int k = 0; k < nb; ++k) {
         const int b = blks[k];
-        const double w = blk_w[b];
-        const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
-        for (int i = 0; i < 6; ++i) {
-            for (int j = i; j < 6; ++j) H[i * 6 + j] += w * acc[hidx(d.PL, i, j)];
-            gl[i] += w * acc[d.NH + i];
-        }
-    }
-    for (int i = 0; i < 6; ++i) gp[i] = gl[i];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < i; ++j) H[i * 6 + j] = H[j * 6 + i];
-    if (init_scale)
-        for (int i = 0; i < 6; ++i) { const double s = 1.0 / (1.0 + sqrt(H[i * 6 + i])); scale2[i] = s * s; }
-    // gradient max-norm contribution (trust_region_minimizer.cc: inf-norm of the tangent gradient,
-    // or of Plus(x, -g) - x when the problem is bounds-constrained)
-    double gm = 0.0;
-    if (!constrained) {
-        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
-    } else {
-        const double ng[3] = {-gl[0], -gl[1], -gl[2]};
-        double qn[4];
-        quat_plus(xview7, ng, qn);
-        for (int i = 0; i < 4; ++i) gm = fmax(gm, fabs(qn[i] - xview7[i]));
-        for (int i = 3; i < 6; ++i) gm = fmax(gm, fabs(gl[i]));
-    }
-    *gmax = gm;
-    for (int i = 0; i < 6; ++i) {
-        D[i] = lm_diag(H[i * 6 + i], scale2[i], radius);
-        H[i * 6 + i] += D[i];
-    }
-    const bool ok = chol6(H);  // H now holds the factor: every substitution below reads this local copy, not L
-    for (int i = 0; i < 36; ++i) L[i] = H[i];
-    double yl[6], rd[6];
-    for (int i = 0; i < 6; ++i) { yl[i] = gl[i]; rd[i] = 1.0 / H[i * 6 + i]; }
-    if (ok) fwd6r(H, rd, yl);
-    for (int i = 0; i < 6; ++i) y[i] = yl[i];
-    if (!ok) return false;
-    for (int k = 0; k < nb; ++k) {
-        const int b = blks[k];
-        const double w = blk_w[b];
-        const double* acc = blk_acc + static_cast<long long>(b) * d.NACC;
-        double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
-        for (int c = 0; c < d.PSH; ++c) {
-            double e[6];
-            for (int i = 0; i < 6; ++i) e[i] = w * acc[hidx(d.PL, i, 6 + c)];
-            fwd6r(H, rd, e);
-            for (int i = 0; i < 6; ++i) Z[i * d.PSH + c] = e[i];
-        }
+        for (int c = 0; c < d.PSH; ++c)
+            schur_view_zcol(d, F, rd, blk_w[b], blk_acc + static_cast<long long>(b) * d.NACC, c, blk_Z + static_cast<long long>(b) * 6 * d.PSH);
     }
     return true;
 }
@@ -149,9 +166,10 @@ CBA_HD bool schur_view_body(const SchurDims& d, int nb, const int32_t* blks, con
 // two are the terms of Ceres' model_cost_change = -g^T d - 1/2 d^T H d that involve the private block:
 //   g_p^T d_p   and   d_p^T H_pp d_p + 2 d_p^T E d_c  =  |rhs|^2 - d_p^T D d_p - 2 rhs^T a,
 // with a = Z d_c, rhs = y + a = -L^T d_p, H_pp = L L^T - D, E = L Z.
-CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, const int32_t* blk_cam, const double* blk_Z,
-                              const double* delta_sh, bool fixed, const double* L, const double* y, const double* D,
-                              const double* gp, const double* x7, double* delta_p, double* xt7, double* out4) {
+// (two pieces again: a = Z d_c is a sum over the view's blocks and shared columns that a wavefront can split, the rest is a short
+// serial chain — backend_hip.hip k_backsub_wave; the serial form is the two in sequence)
+CBA_HD void backsub_view_finish(bool fixed, const double* a, const double* L, const double* y, const double* D, const double* gp,
+                                const double* x7, double* delta_p, double* xt7, double* out4) {
     double xn = 0.0;
     for (int i = 0; i < 7; ++i) xn += x7[i] * x7[i];
     out4[1] = fixed ? 0.0 : xn;  // constant blocks are not part of Ceres' reduced state vector
@@ -161,18 +179,7 @@ CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, c
         out4[0] = out4[2] = out4[3] = 0.0;
         return;
     }
-    double a[6], rhs[6];
-    for (int i = 0; i < 6; ++i) a[i] = 0.0;
-    for (int k = 0; k < nb; ++k) {
-        const int b = blks[k];
-        const double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
-        const double* dc = delta_sh + blk_cam[b] * d.PC;
-        for (int i = 0; i < 6; ++i) {
-            double s = 0.0;
-            for (int c = 0; c < d.PSH; ++c) s += Z[i * d.PSH + c] * dc[c];
-            a[i] += s;
-        }
-    }
+    double rhs[6];
     double rr = 0.0, ra = 0.0;
     for (int i = 0; i < 6; ++i) { rhs[i] = y[i] + a[i]; rr += rhs[i] * rhs[i]; ra += rhs[i] * a[i]; }
     bwd6(L, rhs);
@@ -185,6 +192,25 @@ CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, c
     out4[0] = s2;
     out4[2] = gd;
     out4[3] = rr - dDd - 2.0 * ra;
+}
+
+CBA_HD void backsub_view_body(const SchurDims& d, int nb, const int32_t* blks, const int32_t* blk_cam, const double* blk_Z,
+                              const double* delta_sh, bool fixed, const double* L, const double* y, const double* D,
+                              const double* gp, const double* x7, double* delta_p, double* xt7, double* out4) {
+    double a[6];
+    for (int i = 0; i < 6; ++i) a[i] = 0.0;
+    if (!fixed)
+        for (int k = 0; k < nb; ++k) {
+            const int b = blks[k];
+            const double* Z = blk_Z + static_cast<long long>(b) * 6 * d.PSH;
+            const double* dc = delta_sh + blk_cam[b] * d.PC;
+            for (int i = 0; i < 6; ++i) {
+                double s = 0.0;
+                for (int c = 0; c < d.PSH; ++c) s += Z[i * d.PSH + c] * dc[c];
+                a[i] += s;
+            }
+        }
+    backsub_view_finish(fixed, a, L, y, D, gp, x7, delta_p, xt7, out4);
 }
 
 // Line search (line_search.hpp): the private pose of a view at step size a along the step of the last back-substitution,
