@@ -13,6 +13,7 @@ Tolerances (fp64):
 """
 import copy
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -720,9 +721,10 @@ def test_full_size_c3_properties(gpu_lib, lm_mode):
         xs = h.solve_stats()
         # one exchange point per LM step (a no-op on a single rank): the initial system, one per trial point, one more only for a
         # rejected step, a radius miss, or a step accepted after a plain trial
-        assert xs["speculative_steps"] >= 1 and xs["speculation_hits"] >= 1
-        assert xs["allreduce_calls"] == 1 + s.iterations + xs["speculation_misses"] + xs["rejected_steps"] + xs["line_search_evaluations"] + (
-            s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"])
+        if os.environ.get("CBA_LM_SPECULATE", "1") != "0":  # the plain protocol (a selectable knob) exchanges twice per step
+            assert xs["speculative_steps"] >= 1 and xs["speculation_hits"] >= 1
+            assert xs["allreduce_calls"] == 1 + s.iterations + xs["speculation_misses"] + xs["rejected_steps"] + xs[
+                "line_search_evaluations"] + (s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"])
         cs = h.covariance_shared(o)
         cs_err = gpu_lib.cba_last_error().decode() if cs is None else ""
         # the same solve again from the same start on the same handle: bitwise identical end state

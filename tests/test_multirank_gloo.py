@@ -249,3 +249,104 @@ def test_axxb_sharded_over_ranks_matches_one_gpu(tmp_path, n_poses, world):
         assert np.abs(r["cov"] - ref.core.covariance).max() <= 1e-8 * np.abs(ref.core.covariance).max()
     for r in res[1:]:  # every rank ran the same LM on the same sums
         assert np.array_equal(res[0]["pose"], r["pose"])
+
+
+# ---- CPU tier: many random problems over 2-4 IN-PROCESS ranks (threads; the all-reduce is a barrier + sum in Python) ------------------
+def _threaded_solve(hm, flats, okw, timeout=60.0):
+    """Solve the shards `flats` concurrently, one thread per rank, with hm_reproj_solve_ex; returns (summaries, stats).  Every rank
+    must issue the same sequence of all-reduces with the same sizes: a mismatch breaks the barrier (timeout) instead of hanging."""
+    import threading
+
+    from calibration_amd import capi
+    from calibration_amd.capi import CbaSummary
+    from tests import helpers
+
+    world = len(flats)
+    barrier = threading.Barrier(world, timeout=timeout)
+    slots, sizes = [None] * world, [[] for _ in range(world)]
+    out, errs = [None] * world, []
+
+    def run(rank):
+        def allreduce(buf, count, _user):
+            arr = np.ctypeslib.as_array(buf, shape=(int(count),))
+            slots[rank] = arr.copy()
+            sizes[rank].append(int(count))
+            barrier.wait()
+            total = np.sum([slots[r] for r in range(world)], axis=0)  # the same order on every rank: bit-identical sums
+            barrier.wait()
+            arr[...] = total
+            return 0
+
+        try:
+            cb = capi.ALLREDUCE_FN(allreduce)
+            d = flats[rank].struct()
+            s = CbaSummary()
+            xs = (C.c_int64 * 8)()
+            o = helpers.options(epsilon=1e-10, **okw)
+            st = hm.hm_reproj_solve_ex(C.byref(d), C.byref(o), cb, None, world, rank, -1, C.byref(s), xs)
+            assert st == 0, hm.hm_last_error()
+            out[rank] = (s, [int(v) for v in xs])
+        except Exception as ex:  # noqa: BLE001
+            errs.append((rank, repr(ex)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout + 30)
+    assert not errs, errs
+    assert all(sizes[0] == sz for sz in sizes), "ranks issued different exchange sequences"
+    return out
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_problems_over_in_process_ranks(hostmath, case):
+    """The multi-rank protocol on random problems, including the rare paths: rough starts (line-search samples, rejected steps,
+    radius misses, plain trials), more ranks than views (empty shards), loss on / off, intrinsics fixed / free.  Every rank must
+    issue the same exchange sequence, end bit-identical in the replicated blocks and agree with the 1-rank solve."""
+    from calibration_amd import capi, synth
+    from calibration_amd.capi import CbaSummary
+    from tests import helpers
+
+    rng = np.random.default_rng(1000 + case)
+    kind = ["intr", "ext", "bundle"][case % 3]
+    world = int(rng.integers(2, 5))
+    rough = bool(rng.integers(0, 2))
+    okw = dict(huber_delta=float(rng.choice([1.0, -1.0, 0.3])))
+    if kind != "intr":
+        okw.update(optimize_intrinsics=int(rng.integers(0, 2)), optimize_extrinsics=int(rng.integers(0, 2)))
+    if kind == "bundle":
+        okw.update(optimize_target_pose=int(rng.integers(0, 2)))
+    seed = int(rng.integers(1, 10_000))
+    nv = int(rng.integers(2, 8))
+
+    def make():
+        if kind == "intr":
+            sc = synth.scene_intrinsics(max(nv, 4), noise_px=0.3, seed=seed, spacing=0.06)
+        elif kind == "ext":
+            sc = synth.scene_extrinsics(nv, 2, noise_px=0.3, seed=seed, spacing=0.06)
+        else:
+            sc = synth.scene_bundle(nv + 4, 2, noise_px=0.3, seed=seed, spacing=0.04)
+        if rough:
+            sc.flat.intr[:, 5:10] = 0.0
+            sc.flat.intr[:, 0:2] *= 0.85
+        return sc
+
+    ref = make().flat
+    d = ref.struct()
+    s1 = CbaSummary()
+    o = helpers.options(epsilon=1e-10, **okw)
+    assert hostmath.hm_reproj_solve(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, C.byref(s1)) == 0
+    full = make().flat
+    flats = [synth.shard_views(full, r, world) for r in range(world)]
+    res = _threaded_solve(hostmath, flats, okw)
+    for (s, xs), f in zip(res, flats):
+        assert s.termination == s1.termination and abs(s.iterations - s1.iterations) <= 2, (s.report, s1.report)
+        assert abs(s.final_cost - s1.final_cost) <= 1e-8 * max(1.0, s1.final_cost)
+        assert np.array_equal(f.intr, flats[0].intr)
+        if f.cam_pose is not None:
+            assert np.array_equal(f.cam_pose, flats[0].cam_pose)
+        assert helpers.rel_diff(ref.intr, f.intr) <= 1e-6
+        calls, _n, spec, hits, misses, rejected, _ls, ls_evals = xs
+        assert calls == 1 + s.iterations + misses + rejected + (s.successful_steps - hits - misses) + ls_evals or s.iterations == 0
