@@ -252,40 +252,27 @@ def test_axxb_sharded_over_ranks_matches_one_gpu(tmp_path, n_poses, world):
 
 
 # ---- CPU tier: many random problems over 2-4 IN-PROCESS ranks (threads; the all-reduce is a barrier + sum in Python) ------------------
-def _threaded_solve(hm, flats, okw, timeout=60.0):
-    """Solve the shards `flats` concurrently, one thread per rank, with hm_reproj_solve_ex; returns (summaries, stats).  Every rank
-    must issue the same sequence of all-reduces with the same sizes: a mismatch breaks the barrier (timeout) instead of hanging."""
+def _in_process_ranks(world, body, timeout=60.0):
+    """Run body(rank, reduce) on `world` threads; reduce(arr) sums a float64 array in place over the ranks (barrier + sum in a fixed
+    order: bit-identical on every rank).  Every rank must issue the same sequence of all-reduces with the same sizes: a mismatch
+    breaks the barrier (timeout) instead of hanging.  Returns the list of body results."""
     import threading
 
-    from calibration_amd import capi
-    from calibration_amd.capi import CbaSummary
-    from tests import helpers
-
-    world = len(flats)
     barrier = threading.Barrier(world, timeout=timeout)
     slots, sizes = [None] * world, [[] for _ in range(world)]
     out, errs = [None] * world, []
 
     def run(rank):
-        def allreduce(buf, count, _user):
-            arr = np.ctypeslib.as_array(buf, shape=(int(count),))
+        def reduce(arr):
             slots[rank] = arr.copy()
-            sizes[rank].append(int(count))
+            sizes[rank].append(arr.size)
             barrier.wait()
-            total = np.sum([slots[r] for r in range(world)], axis=0)  # the same order on every rank: bit-identical sums
+            total = np.sum([slots[r] for r in range(world)], axis=0)
             barrier.wait()
             arr[...] = total
-            return 0
 
         try:
-            cb = capi.ALLREDUCE_FN(allreduce)
-            d = flats[rank].struct()
-            s = CbaSummary()
-            xs = (C.c_int64 * 8)()
-            o = helpers.options(epsilon=1e-10, **okw)
-            st = hm.hm_reproj_solve_ex(C.byref(d), C.byref(o), cb, None, world, rank, -1, C.byref(s), xs)
-            assert st == 0, hm.hm_last_error()
-            out[rank] = (s, [int(v) for v in xs])
+            out[rank] = body(rank, reduce)
         except Exception as ex:  # noqa: BLE001
             errs.append((rank, repr(ex)))
             barrier.abort()
@@ -300,19 +287,39 @@ def _threaded_solve(hm, flats, okw, timeout=60.0):
     return out
 
 
-@pytest.mark.parametrize("case", range(24))
-def test_random_problems_over_in_process_ranks(hostmath, case):
-    """The multi-rank protocol on random problems, including the rare paths: rough starts (line-search samples, rejected steps,
-    radius misses, plain trials), more ranks than views (empty shards), loss on / off, intrinsics fixed / free.  Every rank must
-    issue the same exchange sequence, end bit-identical in the replicated blocks and agree with the 1-rank solve."""
-    from calibration_amd import capi, synth
+def _threaded_solve(hm, flats, okw):
+    """Solve the shards `flats` concurrently with hm_reproj_solve_ex (the LM driver over the host-math backend); (summary, stats)."""
+    from calibration_amd import capi
     from calibration_amd.capi import CbaSummary
     from tests import helpers
+
+    world = len(flats)
+
+    def body(rank, reduce):
+        def allreduce(buf, count, _user):
+            reduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+            return 0
+
+        cb = capi.ALLREDUCE_FN(allreduce)
+        d = flats[rank].struct()
+        s = CbaSummary()
+        xs = (C.c_int64 * 8)()
+        o = helpers.options(epsilon=1e-10, **okw)
+        st = hm.hm_reproj_solve_ex(C.byref(d), C.byref(o), cb, None, world, rank, -1, C.byref(s), xs)
+        assert st == 0, hm.hm_last_error()
+        return s, [int(v) for v in xs]
+
+    return _in_process_ranks(world, body)
+
+
+def _random_case(case):
+    """(kind, world, okw, make) of random problem `case`: make() builds the scene afresh (same seed: identical data)."""
+    from calibration_amd import synth
 
     rng = np.random.default_rng(1000 + case)
     kind = ["intr", "ext", "bundle"][case % 3]
     world = int(rng.integers(2, 5))
-    rough = bool(rng.integers(0, 2))
+    rough = bool(rng.integers(0, 2)) or case % 4 != 0  # most cases start far away
     okw = dict(huber_delta=float(rng.choice([1.0, -1.0, 0.3])))
     if kind != "intr":
         okw.update(optimize_intrinsics=int(rng.integers(0, 2)), optimize_extrinsics=int(rng.integers(0, 2)))
@@ -328,11 +335,28 @@ def test_random_problems_over_in_process_ranks(hostmath, case):
             sc = synth.scene_extrinsics(nv, 2, noise_px=0.3, seed=seed, spacing=0.06)
         else:
             sc = synth.scene_bundle(nv + 4, 2, noise_px=0.3, seed=seed, spacing=0.04)
-        if rough:
+        if rough:  # far enough from the optimum for rejected steps, radius misses and (with bounds) line-search samples
+            r2 = np.random.default_rng(case)
             sc.flat.intr[:, 5:10] = 0.0
-            sc.flat.intr[:, 0:2] *= 0.85
+            sc.flat.intr[:, 0:2] *= r2.uniform(0.5, 0.75)
+            sc.flat.intr[:, 2:4] *= r2.uniform(0.85, 1.15, size=2)
+            if sc.flat.view_pose is not None:
+                sc.flat.view_pose[..., 6] *= r2.uniform(0.7, 1.4)
         return sc
 
+    return kind, world, okw, make
+
+
+@pytest.mark.parametrize("case", range(36))
+def test_random_problems_over_in_process_ranks(hostmath, case):
+    """The multi-rank protocol on random problems, including the rare paths: rough starts (line-search samples, rejected steps,
+    radius misses, plain trials), more ranks than views (empty shards), loss on / off, intrinsics fixed / free.  Every rank must
+    issue the same exchange sequence, end bit-identical in the replicated blocks and agree with the 1-rank solve."""
+    from calibration_amd import capi, synth
+    from calibration_amd.capi import CbaSummary
+    from tests import helpers
+
+    _kind, world, okw, make = _random_case(case)
     ref = make().flat
     d = ref.struct()
     s1 = CbaSummary()
@@ -350,3 +374,38 @@ def test_random_problems_over_in_process_ranks(hostmath, case):
         assert helpers.rel_diff(ref.intr, f.intr) <= 1e-6
         calls, _n, spec, hits, misses, rejected, _ls, ls_evals = xs
         assert calls == 1 + s.iterations + misses + rejected + (s.successful_steps - hits - misses) + ls_evals or s.iterations == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(36))
+def test_random_problems_over_in_process_ranks_gpu(case):
+    """The same random problems on the REAL engine: one handle per rank on GPU 0, each driven from its own thread, the packed
+    all-reduce through the host-callback transport.  Same exchange sequence on every rank, replicated blocks bit-identical,
+    1-rank GPU solve reproduced."""
+    from calibration_amd import optim, synth
+    from tests import helpers
+
+    _kind, world, okw, make = _random_case(case)
+    ref = make().flat
+    o = helpers.options(epsilon=1e-10, **okw)
+    with optim.ReprojHandle(ref, device=0) as h:
+        s1 = h.solve(o)
+    full = make().flat
+    flats = [synth.shard_views(full, r, world) for r in range(world)]
+
+    def body(rank, reduce):
+        with optim.ReprojHandle(flats[rank], device=0) as h:
+            h.set_allreduce(reduce, world, rank)
+            s = h.solve(helpers.options(epsilon=1e-10, **okw))
+            return s, h.solve_stats()
+
+    res = _in_process_ranks(world, body, timeout=120.0)
+    for (s, xs), f in zip(res, flats):
+        assert s.termination == s1.termination and abs(s.iterations - s1.iterations) <= 2, (s.report, s1.report)
+        assert abs(s.final_cost - s1.final_cost) <= 1e-8 * max(1.0, s1.final_cost)
+        assert np.array_equal(f.intr, flats[0].intr)
+        if f.cam_pose is not None:
+            assert np.array_equal(f.cam_pose, flats[0].cam_pose)
+        assert helpers.rel_diff(ref.intr, f.intr) <= 1e-6
+        assert xs["allreduce_calls"] == 1 + s.iterations + xs["speculation_misses"] + xs["rejected_steps"] + xs[
+            "line_search_evaluations"] + (s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"]) or s.iterations == 0
