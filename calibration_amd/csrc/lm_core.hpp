@@ -257,7 +257,9 @@ class LMDriver {
                 TrialStats st;
                 double step2_sh = 0, xnorm2_sh = 0, model_change = 0;
                 bool speculated = false;
-                const double radius_spec = std::min(max_radius, 3.0 * radius);
+                // the radius a gain ratio >= 0.937 leads to, in the arithmetic of the update below (radius / (1/3) differs from
+                // 3 * radius by one ulp for a quarter of all doubles: the comparison after the step is exact)
+                const double radius_spec = std::min(max_radius, radius / (1.0 / 3.0));
                 if (valid) {
                     shared_plus(delta, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
                     be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());

@@ -215,6 +215,9 @@ def test_covariance_matches_oracle(gpu_lib, oracle):
         nz = d0 > 0
         scale = np.sqrt(np.outer(d0[nz], d0[nz]))
         assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / scale).max() <= 1e-5
+        with optim.ReprojHandle(a.flat) as h:  # at the SAME point (the oracle's end point) the two assemblies differ by rounding only
+            cov1a = h.covariance(o)
+        assert (np.abs(cov0 - cov1a)[np.ix_(nz, nz)] / scale).max() <= 1e-7
         with optim.ReprojHandle(b.flat) as h:  # shared-block marginal = leading block of the full matrix, O(#views) work
             cs = h.covariance_shared(o)
         assert cs is not None and np.array_equal(cs, cov1[:cs.shape[0], :cs.shape[0]])

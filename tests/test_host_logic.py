@@ -368,6 +368,13 @@ def test_covariance_assembly_matches_oracle(oracle, hostmath, kind):
     assert np.array_equal(d0 == 0, np.diag(cov1) == 0)
     nz = d0 > 0
     assert (np.abs(cov0 - cov1)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-5
+    # ... and at the SAME parameter point (the oracle's) the two assemblies - the oracle's QR of the ambient Jacobian, the
+    # product's Schur complement + gauge lift - differ by rounding only: the 1e-5 above is the two solves' end points (1e-9
+    # apart) seen through the problem's conditioning, not the covariance arithmetic
+    da = a.flat.struct()
+    cov1a = np.zeros((n, n))
+    assert hostmath.hm_reproj_covariance(C.byref(da), C.byref(o), dptr(cov1a)) == 0, hostmath.hm_last_error()
+    assert (np.abs(cov0 - cov1a)[np.ix_(nz, nz)] / np.sqrt(np.outer(d0[nz], d0[nz]))).max() <= 1e-7
     # the shared-block marginal is exactly the leading rows/columns of the full matrix
     ns = int(hostmath.hm_reproj_covariance_shared_dim(C.byref(d)))
     per_cam = b.flat.intr.shape[-1] + (0 if kind == "intr" else 7)
