@@ -45,14 +45,25 @@ __global__ __launch_bounds__(256) void k_weights_cost(int n_blocks, int NACC, in
                                                       double* __restrict__ out) {
     __shared__ double sh[2][256];
     double c = 0.0, ss = 0.0;
-    for (int b = static_cast<int>(threadIdx.x); b < n_blocks; b += 256) {
-        const double s = blk_acc[static_cast<int64_t>(b) * NACC + s_idx];
-        double rho, w;
-        huber(s, huber_delta, &rho, &w);
-        blk_w[b] = w;
-        blk_s[b] = s;
-        c += 0.5 * rho;
-        ss += s;
+    // four independent loads in flight per thread (each is a cache line of its own: one block's |r|^2), summed in the same order
+    for (int b0 = static_cast<int>(threadIdx.x); b0 < n_blocks; b0 += 4 * 256) {
+        double sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * 256;
+            sv[q] = b < n_blocks ? blk_acc[static_cast<int64_t>(b) * NACC + s_idx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * 256;
+            if (b >= n_blocks) break;
+            double rho, w;
+            huber(sv[q], huber_delta, &rho, &w);
+            blk_w[b] = w;
+            blk_s[b] = sv[q];
+            c += 0.5 * rho;
+            ss += sv[q];
+        }
     }
     sh[0][threadIdx.x] = c;
     sh[1][threadIdx.x] = ss;
@@ -75,9 +86,18 @@ __global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, c
     const int64_t p0 = chunk_off[k], p1 = chunk_off[k + 1];
     for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
         double s = 0.0;
-        for (int64_t p = p0; p < p1; ++p) {
-            const int b = cam_blk[p];
-            s += blk_w[b] * blk_acc[static_cast<int64_t>(b) * NACC + e];
+        for (int64_t p = p0; p < p1; p += 4) {  // four block rows in flight, added in list order
+            double a[4], w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = p + q < p1;
+                const int b = in ? cam_blk[p + q] : 0;
+                w[q] = in ? blk_w[b] : 0.0;
+                a[q] = in ? blk_acc[static_cast<int64_t>(b) * NACC + e] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p + q < p1) s += w[q] * a[q];
         }
         partial[static_cast<int64_t>(k) * NACC + e] = s;
     }
@@ -687,6 +707,21 @@ struct HipBackend final : Backend {
         CBA_HIP(hipGetLastError());
     }
     // sum [off, off + count) of the packed buffer over the ranks and bring it to `pack` on the host
+    void wait_step() {
+        if (!st.sync_spin) { CBA_HIP(hipStreamSynchronize(e.stream)); return; }
+        if (!st.step_done) CBA_HIP(hipEventCreateWithFlags(&st.step_done, hipEventDisableTiming));
+        CBA_HIP(hipEventRecord(st.step_done, e.stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(st.step_done);
+            if (q == hipSuccess) return;
+            if (q != hipErrorNotReady) CBA_HIP(q);
+            __builtin_ia32_pause();
+            // a long stage (Mode B over 1e7+ observations) gains nothing from polling: sleep after 300 us
+            if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        }
+        CBA_HIP(hipStreamSynchronize(e.stream));
+    }
     void exchange(int64_t off, int64_t count, const AllReduce& ar, double* pack) {
         if (e.rccl_comm) {  // RCCL over xGMI, in place on the device buffer, on the engine's stream: no host staging
             const ncclResult_t r = ncclAllReduce(st.pack_dev.p + off, st.pack_dev.p + off, static_cast<size_t>(count), ncclDouble, ncclSum,
@@ -696,7 +731,7 @@ struct HipBackend final : Backend {
             device_allreduce_doubles += count;
             st.pack_dev.download(st.pin_packed.p + off, static_cast<size_t>(count), e.stream, static_cast<size_t>(off));
         }
-        CBA_HIP(hipStreamSynchronize(e.stream));
+        wait_step();
         if (!e.rccl_comm) ar(st.pin_packed.p + off, count);  // host transport (gloo / MPI callback) or a single rank
         std::memcpy(pack + off, st.pin_packed.p + off, sizeof(double) * static_cast<size_t>(count));
     }
@@ -919,6 +954,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     }
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
     if (const char* env = std::getenv("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
+    if (const char* env = std::getenv("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);
         st->graphs_ok = v != 0;

@@ -342,19 +342,26 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
     }
 }
 
-// blk_acc[b] = packed [H | g | s] of block b from its moment row; one wavefront per block, G in LDS
+// blk_acc[b] = packed [H | g | s] of block b from its moment row; one wavefront per block, G and T = Qh Gh in LDS
 template <int CHAIN, int PI>
 __global__ __launch_bounds__(64) void k_mom_expand(int n_blocks, const double* __restrict__ bc, const double* __restrict__ blk_mom,
                                                    double* __restrict__ blk_acc) {
-    constexpr int PL = 12 + PI, NACC = PL * (PL + 1) / 2 + PL + 1, NMOM = MomLayout<PI>::N;
+    constexpr int PL = 12 + PI, NH = PL * (PL + 1) / 2, NACC = NH + PL + 1, NMOM = MomLayout<PI>::N;
+    static constexpr UpperIndex<PL> UI{};
     __shared__ double G[3][36];
+    __shared__ double T[9 * 12];
     __shared__ double mom[NMOM];
     const int b = blockIdx.x;
     if (b >= n_blocks) return;
-    if (threadIdx.x == 0) pose_affine_G<CHAIN>(bc + static_cast<int64_t>(b) * BC_SIZE, G);
+    if (threadIdx.x < 3) pose_affine_G_part<CHAIN>(bc + static_cast<int64_t>(b) * BC_SIZE, threadIdx.x, G[threadIdx.x]);
     for (int e = threadIdx.x; e < NMOM; e += 64) mom[e] = blk_mom[static_cast<int64_t>(b) * NMOM + e];
     __syncthreads();
-    for (int e = threadIdx.x; e < NACC; e += 64) blk_acc[static_cast<int64_t>(b) * NACC + e] = mom_expand_entry<PI>(mom, G, e);
+    for (int e = threadIdx.x; e < 9 * 12; e += 64) T[e] = mom_expand_T<PI>(mom, G, e / 12, e % 12);
+    __syncthreads();
+    for (int e = threadIdx.x; e < NACC; e += 64) {
+        const int i = e < NH ? UI.i[e] : 0, j = e < NH ? UI.j[e] : 0;
+        blk_acc[static_cast<int64_t>(b) * NACC + e] = mom_expand_entry_T<PI>(mom, G, T, e, i, j);
+    }
 }
 
 // ---- launchers --------------------------------------------------------------------------------

@@ -245,6 +245,13 @@ class LMDriver {
         double rel_last = 0.0, rel_prev = 0.0;
 
         auto done = [&](int t, const char* m) { term = t; msg = m; };
+        // CBA_LM_TIMING=1: where the host side of the iteration spends its time (printed once per solve)
+        static const bool timing = [] { const char* e = std::getenv("CBA_LM_TIMING"); return e && e[0] == '1'; }();
+        double t_reduced = 0, t_step = 0, t_adopt = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
         if (gmax_ <= eps) {
             done(CBA_TERM_CONVERGENCE, "Gradient tolerance reached.");
         } else {
@@ -253,7 +260,9 @@ class LMDriver {
                 if (gmax_ <= eps) { done(CBA_TERM_CONVERGENCE, "Gradient tolerance reached."); break; }
                 if (radius <= min_radius) { done(CBA_TERM_CONVERGENCE, "Minimum trust region radius reached."); break; }
                 ++iter;
+                const auto tr0 = now();
                 bool valid = solve_reduced(radius, delta);
+                t_reduced += us(tr0, now());
                 TrialStats st;
                 double step2_sh = 0, xnorm2_sh = 0, model_change = 0;
                 bool speculated = false;
@@ -264,8 +273,10 @@ class LMDriver {
                     shared_plus(delta, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
                     be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
                     const bool expect_convergence = rel_prev > 0.0 && rel_last > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) <= 4.0 * eps;
+                    const auto ts0 = now();
                     if (speculate_ && !plain_next && !expect_convergence)
                         speculated = be_.sys_step(delta.data(), huber, radius_spec, constrained_, L_, ar_, rank_, pack_.data());
+                    t_step += us(ts0, now());
                     if (speculated) {  // statistics and the next system arrived in the same exchange
                         ++xs_.speculative_steps;
                         st.gd = pack_[L_.stats + PackLayout::GD]; st.dHd = pack_[L_.stats + PackLayout::DHD];
@@ -362,8 +373,10 @@ class LMDriver {
                     decrease_factor = 2.0;
                     plain_next = false;
                     if (speculated) {
+                        const auto ta0 = now();
                         be_.accept_step();  // the trial linearisation (block sums, weights, poses) becomes the current one
                         adopt_system(false);
+                        t_adopt += us(ta0, now());
                         if (radius != radius_spec) {  // gain ratio below 0.937: the elimination was made with another radius
                             ++xs_.speculation_misses;
                             resolve(radius);
@@ -395,6 +408,9 @@ class LMDriver {
         out->initial_cost = initial_cost;
         out->final_cost = cost_;
         out->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timing)
+            std::fprintf(stderr, "[cba timing] solve %.1f us, %d iterations: reduced solve %.1f, speculative step (queue + wait + exchange) %.1f, "
+                         "accept + adopt %.1f us\n", out->solve_seconds * 1e6, iter, t_reduced, t_step, t_adopt);
         std::snprintf(out->report, sizeof(out->report), "calibba(schur LM, %d rank%s): %s iters=%d cost %.6e -> %.6e", n_ranks_,
                       n_ranks_ > 1 ? "s" : "", msg, iter, initial_cost, cost_);
     }

@@ -24,6 +24,11 @@ struct HipLMState {
     // the packed exchange buffer of a linear solve (lm_core.hpp PackLayout): assembled and all-reduced on the device
     DevBuf<double> pack_dev, sys_tiles, stat_dev;
     PinnedBuf<double> pin_packed;
+    // the ONE wait of an LM step: hipStreamSynchronize sleeps on an interrupt (20-50 us to wake up on ROCm 7.2, more than the
+    // whole host side of a step); polling an event recorded behind the stage returns within a few us (CBA_SYNC_SPIN=0: sleep)
+    hipEvent_t step_done = nullptr;
+    int sync_spin = 1;
+    ~HipLMState() { if (step_done) (void)hipEventDestroy(step_done); }
     int64_t xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ExchangeStats of the last solve (cba_reproj_solve_stats)
     // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
     // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size

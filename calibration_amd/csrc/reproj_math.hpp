@@ -289,39 +289,43 @@ CBA_HD void reproj_point(const T* bc, const T* intr, const T* sd, T X, T Y, T uo
 // BUNDLE: 2 [X m1 + Y m2 + p0]x N and -N.)  Mode B of the two-pose chains therefore accumulates MOMENTS of
 // Q = du du^T + dv dv^T etc. instead of the 12-column blocks (k_normal_eq_mom), and this routine expands a block's
 // moments into the packed [H | g | s] row.  G[a] is row-major 3 x 12.
+// G[a] alone (a = 0: constant term, 1: X, 2: Y): the three are independent, three lanes of k_mom_expand fill one each
 template <int CHAIN>
-CBA_HD void pose_affine_G(const double* bc, double G[3][36]) {
-    for (int a = 0; a < 3; ++a) for (int i = 0; i < 36; ++i) G[a][i] = 0.0;
+CBA_HD void pose_affine_G_part(const double* bc, int a, double* Ga /*3 x 12 row-major*/) {
+    for (int i = 0; i < 36; ++i) Ga[i] = 0.0;
     const double* M = bc + BC_M;
     auto skew_cols = [](const double* v, double* S /*3x3 row-major [v]x*/) {
         S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
     };
-    // pose A rotation: -2 M [a_k]x for X (a1) and Y (a2); translation: M (constant)
-    for (int a = 1; a <= 2; ++a) {
+    if (a >= 1) {  // pose A rotation: -2 M [a_k]x for X (a1) and Y (a2)
         double S[9], MS[9];
         skew_cols(bc + (a == 1 ? BC_A1 : BC_A2), S);
         mat3_mul(M, S, MS);
-        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + i] = -2.0 * MS[k * 3 + i];
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) Ga[k * 12 + i] = -2.0 * MS[k * 3 + i];
+    } else {  // pose A translation: M (constant)
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) Ga[k * 12 + 3 + i] = M[k * 3 + i];
     }
-    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[0][k * 12 + 3 + i] = M[k * 3 + i];
     // pose B
-    const double* vec[3] = {bc + BC_P0, bc + BC_M1, bc + BC_M2};
-    for (int a = 0; a < 3; ++a) {
-        double v[3] = {vec[a][0], vec[a][1], vec[a][2]}, S[9];
-        if (CHAIN == CH_EXTRINSIC) {
-            if (a == 0) for (int k = 0; k < 3; ++k) v[k] -= bc[BC_TB + k];
-            skew_cols(v, S);
-            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + 6 + i] = -2.0 * S[k * 3 + i];
-        } else {
-            double SN[9];
-            skew_cols(v, S);
-            mat3_mul(S, bc + BC_N, SN);
-            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) G[a][k * 12 + 6 + i] = 2.0 * SN[k * 3 + i];
-        }
+    const double* vec = bc + (a == 0 ? BC_P0 : (a == 1 ? BC_M1 : BC_M2));
+    double v[3] = {vec[0], vec[1], vec[2]}, S[9];
+    if (CHAIN == CH_EXTRINSIC) {
+        if (a == 0) for (int k = 0; k < 3; ++k) v[k] -= bc[BC_TB + k];
+        skew_cols(v, S);
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) Ga[k * 12 + 6 + i] = -2.0 * S[k * 3 + i];
+    } else {
+        double SN[9];
+        skew_cols(v, S);
+        mat3_mul(S, bc + BC_N, SN);
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) Ga[k * 12 + 6 + i] = 2.0 * SN[k * 3 + i];
     }
-    for (int k = 0; k < 3; ++k)
-        for (int i = 0; i < 3; ++i)
-            G[0][k * 12 + 9 + i] = CHAIN == CH_EXTRINSIC ? (k == i ? 1.0 : 0.0) : -bc[BC_N + k * 3 + i];
+    if (a == 0)
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < 3; ++i)
+                Ga[k * 12 + 9 + i] = CHAIN == CH_EXTRINSIC ? (k == i ? 1.0 : 0.0) : -bc[BC_N + k * 3 + i];
+}
+template <int CHAIN>
+CBA_HD void pose_affine_G(const double* bc, double G[3][36]) {
+    for (int a = 0; a < 3; ++a) pose_affine_G_part<CHAIN>(bc, a, G[a]);
 }
 
 // moment-row layout of one residual block (PI = intrinsics size):
@@ -375,6 +379,55 @@ CBA_HD double mom_expand_entry(const double* mom, const double G[3][36], int e) 
                 for (int l = 0; l < 3; ++l) s += gk * Q[sym3(k, l)] * G[b][l * 12 + j];
             }
         }
+    return s;
+}
+
+// The same expansion in two stages (k_mom_expand): with the stacked 9 x 12 matrix Gh[(a,k)][i] = G[a][k*12+i] and the 9 x 9
+// symmetric Qh[(a,k)][(b,l)] = Qm[(a,b)][(k,l)] the pose-pose block is Gh^T Qh Gh.  T = Qh Gh first (108 entries of 9 products),
+// then every pose-pose entry is 9 products instead of 81.
+template <int PI>
+CBA_HD double mom_expand_T(const double* mom, const double G[3][36], int ak, int j) {
+    using L = MomLayout<PI>;
+    const int a = ak / 3, k = ak % 3;
+    double s = 0.0;
+    for (int b = 0; b < 3; ++b) {
+        const double* Q = mom + L::OFF_Q + 6 * sym3(a, b);
+        for (int l = 0; l < 3; ++l) s += Q[sym3(k, l)] * G[b][l * 12 + j];
+    }
+    return s;
+}
+// (i, j), i <= j, of entry e of a row-major packed upper triangle of width PL
+template <int PL>
+struct UpperIndex {
+    unsigned char i[PL * (PL + 1) / 2], j[PL * (PL + 1) / 2];
+    constexpr UpperIndex() : i(), j() {
+        int e = 0;
+        for (int r = 0; r < PL; ++r)
+            for (int c = r; c < PL; ++c) { i[e] = static_cast<unsigned char>(r); j[e] = static_cast<unsigned char>(c); ++e; }
+    }
+};
+template <int PI>
+CBA_HD double mom_expand_entry_T(const double* mom, const double G[3][36], const double* T /*9 x 12*/, int e, int i, int j) {
+    using L = MomLayout<PI>;
+    constexpr int PL = 12 + PI, NH = PL * (PL + 1) / 2;
+    if (e == NH + PL) return mom[L::OFF_S];
+    if (e >= NH) {  // gradient
+        const int g = e - NH;
+        if (g >= 12) return mom[L::OFF_G + g - 12];
+        double s = 0.0;
+        for (int ak = 0; ak < 9; ++ak) s += G[ak / 3][(ak % 3) * 12 + g] * mom[L::OFF_q + ak];
+        return s;
+    }
+    if (i >= 12) {  // intrinsics-intrinsics
+        const int a = i - 12, b = j - 12;
+        return mom[L::OFF_H + a * PI - a * (a - 1) / 2 + (b - a)];
+    }
+    double s = 0.0;
+    if (j >= 12) {  // pose-intrinsics
+        for (int ak = 0; ak < 9; ++ak) s += G[ak / 3][(ak % 3) * 12 + i] * mom[L::OFF_E + ak * PI + (j - 12)];
+        return s;
+    }
+    for (int ak = 0; ak < 9; ++ak) s += G[ak / 3][(ak % 3) * 12 + i] * T[ak * 12 + j];  // pose-pose
     return s;
 }
 

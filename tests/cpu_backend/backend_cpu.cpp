@@ -82,6 +82,7 @@ struct CpuBackend final : Backend {
             }
         }
     }
+    static int UI_diag(int PL, int i) { return i * PL - i * (i - 1) / 2; }  // packed index of H[i][i]
     // the same blocks through the moment form of the two-pose chains (reproj_math.hpp: mom_point / pose_affine_G / mom_expand_entry)
     template <int CHAIN, int MODEL>
     void mode_b_moments(int which) {
@@ -97,7 +98,19 @@ struct CpuBackend final : Backend {
             double G[3][36];
             pose_affine_G<CHAIN>(&bc[static_cast<size_t>(b) * BC_SIZE], G);
             double* acc = &blk_acc[static_cast<size_t>(b) * s.NACC];
-            for (int e = 0; e < s.NACC; ++e) acc[e] = mom_expand_entry<PI>(mom, G, e);
+            // the two-stage expansion k_mom_expand runs (T = Qh Gh, then 9 products per pose-pose entry), checked entry by entry
+            // against the one-stage definition
+            constexpr int PL = 12 + PI;
+            static constexpr UpperIndex<PL> UI{};
+            double T[9 * 12];
+            for (int e = 0; e < 9 * 12; ++e) T[e] = mom_expand_T<PI>(mom, G, e / 12, e % 12);
+            for (int e = 0; e < s.NACC; ++e) {
+                acc[e] = mom_expand_entry_T<PI>(mom, G, T, e, e < s.NH ? UI.i[e] : 0, e < s.NH ? UI.j[e] : 0);
+                const double one = mom_expand_entry<PI>(mom, G, e);
+                const double scale = std::sqrt(std::fabs(acc[UI_diag(PL, e < s.NH ? UI.i[e] : 0)] * acc[UI_diag(PL, e < s.NH ? UI.j[e] : 0)]));
+                if (std::fabs(acc[e] - one) > 1e-12 * std::max(scale, std::fabs(one)) && e < s.NH && UI.i[e] != UI.j[e])
+                    throw std::runtime_error("two-stage moment expansion differs from the one-stage definition");
+            }
         }
     }
     bool use_moments = false;

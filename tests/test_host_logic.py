@@ -933,3 +933,52 @@ def test_batched_pose_conversions_equal_the_scalar_ones():
     M = poses_to_matrices(P * rng.uniform(0.5, 2.0, size=(len(Ts), 1)) * np.r_[1, 1, 1, 1, 0, 0, 0] + P * np.r_[0, 0, 0, 0, 1, 1, 1])
     assert np.abs(M - np.asarray(Ts)).max() < 1e-12
     assert np.abs(poses_to_matrices(P) - np.stack([pose_to_matrix(p) for p in P])).max() <= 1e-14  # (the norm is summed in another order)
+
+
+def test_dense_cholesky_blocked_and_scalar_forms_solve_the_same_systems():
+    """dense.hpp: the blocked AVX2 + FMA factorisation (taken at run time for n >= 32 on hosts that have both) and the scalar
+    dot-product form, on SPD systems of every size class (multiples of 4, odd tails, below the threshold): L L^T = A and
+    A x = b to rounding against numpy; an indefinite matrix is refused by both."""
+    import subprocess, tempfile, textwrap
+
+    src = textwrap.dedent("""
+        #include <cstdio>
+        #include <cstdlib>
+        #include "dense.hpp"
+        int main(int argc, char** argv) {
+            const int n = std::atoi(argv[1]);
+            const bool indefinite = argc > 2;
+            std::vector<double> A(static_cast<size_t>(n) * n), b(n);
+            for (double& v : A) if (std::scanf("%lf", &v) != 1) return 2;
+            for (double& v : b) if (std::scanf("%lf", &v) != 1) return 2;
+            if (!cba::chol_inplace(A, n)) { std::printf("refused"); std::putchar(10); return indefinite ? 0 : 3; }
+            cba::chol_solve(A, n, b.data());
+            for (int i = 0; i < n; ++i) std::printf("%.17g ", b[i]);
+            std::putchar(10);
+            for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) std::printf("%.17g ", A[static_cast<size_t>(i) * n + j]);
+            std::putchar(10);
+            return 0;
+        }""")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.cpp"), "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "calibration_amd", "csrc"), os.path.join(td, "t.cpp"), "-o", exe], check=True)
+        for n in (3, 31, 32, 33, 70, 120, 122, 123, 257):
+            B = rng.normal(size=(n, n))
+            A = B @ B.T + n * np.eye(n)
+            b = rng.normal(size=n)
+            text = " ".join(repr(float(v)) for v in np.concatenate([A.ravel(), b]))
+            out = subprocess.run([exe, str(n)], input=text, check=True, capture_output=True, text=True).stdout.splitlines()
+            x = np.array([float(v) for v in out[0].split()])
+            L = np.zeros((n, n))
+            L[np.tril_indices(n)] = [float(v) for v in out[1].split()]
+            assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max(), n
+            assert np.abs(x - np.linalg.solve(A, b)).max() <= 1e-11 * np.abs(x).max(), n
+        n = 64
+        A = rng.normal(size=(n, n))
+        A = A + A.T  # symmetric, indefinite
+        out = subprocess.run([exe, str(n), "x"], input=" ".join(repr(float(v)) for v in np.concatenate([A.ravel(), np.zeros(n)])), check=True,
+                             capture_output=True, text=True).stdout
+        assert out.strip() == "refused"
