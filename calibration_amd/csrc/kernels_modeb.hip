@@ -47,8 +47,8 @@ template <int MODEL, int NP, typename T>
 struct MomentForm {
     static constexpr int PI = IntrSize<MODEL>::value;
     static constexpr int NROW = MomRows<PI>::N, NPARTS = NP, NTOT = MomLayout<PI>::N;
-    static constexpr int count(int part) { return (NTOT - part + NP - 1) / NP; }
-    static __device__ __forceinline__ int entry(int part, int l) { return l * NP + part; }
+    static constexpr int count(int part) { return MomSplit<PI, NP>::T.count[part]; }
+    static __device__ __forceinline__ int entry(int part, int l) { return MomSplit<PI, NP>::T.entry[part][l]; }
     static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
         mom_rows<MODEL, T>(bcp, ip, sp, x, y, u, v, w);
     }
@@ -170,8 +170,9 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
     // experiment knobs (read once): CBA_MODEB_DPARTS = parts of the one-pose direct form (2, 3, 4);
     // CBA_MODEB_VARIANT: bits 0-3 = parts of the moment form (2 .. 5), bit 4 = double-buffered rows, >= 32: timing-only ablations
     // Defaults as measured (profiles/r02_modeb_variants.jsonl, ms per pass): one-pose chain, pinhole 2 parts 0.192 / 3: 0.235 / 4: 0.219;
-    // Scheimpflug 2: 0.303 / 3: 0.306 / 4: 0.265; moment form (C3 / 4), pinhole 2: 1.002 / 3: 0.955 / 4: 0.907 / 5: 1.618 (LDS-limited
-    // occupancy), double-buffered rows 0.961 (no gain: the barrier that remains is the one that costs).
+    // Scheimpflug 2: 0.303 / 3: 0.306 / 4: 0.265; moment form (C3 / 4), pinhole 2: 1.075 / 3: 0.939 / 4: 0.830 / 5: 1.415 (LDS-limited
+    // occupancy) with the family-aligned split of MomSplitTable (round-robin entries: 1.002 / 0.955 / 0.907 / 1.618), double-buffered
+    // rows 0.961 (no gain: the barrier that remains is the one that costs).
     static const int dparts_env = std::getenv("CBA_MODEB_DPARTS") ? std::atoi(std::getenv("CBA_MODEB_DPARTS")) : 0;
     static const int variant = std::getenv("CBA_MODEB_VARIANT") ? std::atoi(std::getenv("CBA_MODEB_VARIANT")) : 4;
     const int dparts = dparts_env ? dparts_env : (e.model == CAM_SCHEIMPFLUG ? 4 : 2);

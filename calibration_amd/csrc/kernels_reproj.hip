@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
                                                        double* __restrict__ partial) {
     constexpr int PI = IntrSize<MODEL>::value;
     constexpr int NMOM = MomLayout<PI>::N;
-    constexpr int NLOC = (NMOM + NPARTS - 1) / NPARTS;
+    constexpr int NLOC = MomSplit<PI, NPARTS>::T.count[PART];
     constexpr int NPAD = TransposeSum<16>::pad(NLOC);
     const int64_t w = wave_index();
     if (w >= n_tiles) return;
@@ -337,8 +337,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
     double* out = partial + w * NMOM;
 #pragma unroll
     for (int j = 0; j < TransposeSum<NPAD>::CNT; ++j) {
-        const int e = (base + j) * NPARTS + PART;
-        if (owner && e < NMOM) out[e] = acc[j];
+        if (owner && base + j < NLOC) out[MomSplit<PI, NPARTS>::T.entry[PART][base + j]] = acc[j];
     }
 }
 

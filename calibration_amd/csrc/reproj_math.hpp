@@ -443,6 +443,81 @@ struct MomRows {
     static constexpr bool v_live(int c) { return !(c == 0 || c == 2 || c == 3 || c == 4); }
 };
 
+// Which wavefront ("part") of a Mode B workgroup keeps which entry of the moment row, and in which of its accumulators.
+// The entries come in families that share per-observation products: the 3 PI entries (a, k, j) of Em with the same k share
+// e_kj = du_k Jui_j + dv_k Jvi_j, the 36 of Qm share the six q_kl, the 9 of qm the three du_k r_u + dv_k r_v.  Dealing the entries
+// out round-robin (entry e to part e mod NP, the first form of this kernel) made every part form nearly all of those products:
+// 380 accumulate instructions per observation over the four parts where 276 suffice.  Here whole families go to one part
+// (Em by k, Qm, qm, gradient + |r|^2; the rows of the intrinsics block, which share nothing, fill the parts up), assigned
+// largest-first to the least loaded part by instruction count.  NP = 1 gives the identity.
+template <int PI, int NP>
+struct MomSplitTable {
+    static constexpr int N = MomLayout<PI>::N, NATOM = 6 + PI;
+    short part[N], slot[N], count[NP], entry[NP][N];
+    static constexpr bool hu(int j) { return !(j == 1 || j == 3); }
+    static constexpr bool hv(int j) { return !(j == 0 || j == 2 || j == 4); }
+    // atom -> instruction count (products + accumulations), as mom_accumulate spends them
+    static constexpr int atom_cost(int t) {
+        if (t < 3) {  // Em, fixed k
+            int c = 3 * PI;
+            for (int j = 0; j < PI; ++j) c += (hu(j) && j != 2 ? 1 : 0) + (hv(j) && j != 3 ? 1 : 0);
+            return c;
+        }
+        if (t == 3) return 12 + 3 + 36;  // Qm
+        if (t == 4) return 15;           // qm
+        if (t == 5) {                    // gradient, |r|^2
+            int c = 2;
+            for (int j = 0; j < PI; ++j) c += (hu(j) ? 1 : 0) + (hv(j) ? 1 : 0);
+            return c;
+        }
+        const int a = t - 6;             // row a of the intrinsics block
+        int c = 0;
+        for (int b = a; b < PI; ++b) c += (hu(a) && hu(b) ? 1 : 0) + (hv(a) && hv(b) ? 1 : 0);
+        return c;
+    }
+    static constexpr int atom_of(int e) {
+        using L = MomLayout<PI>;
+        if (e < L::OFF_q) return 3;
+        if (e < L::OFF_E) return 4;
+        if (e < L::OFF_H) return ((e - L::OFF_E) / PI) % 3;  // (a * 3 + k) * PI + j
+        if (e >= L::OFF_G) return 5;
+        int a = 0, rem = e - L::OFF_H;
+        while (rem >= PI - a) { rem -= PI - a; ++a; }
+        return 6 + a;
+    }
+    constexpr MomSplitTable() : part(), slot(), count(), entry() {
+        int load[NP] = {}, where[NATOM] = {};
+        bool done[NATOM] = {};
+        for (int n = 0; n < NATOM; ++n) {
+            int best = -1;
+            for (int t = 0; t < NATOM; ++t)
+                if (!done[t] && (best < 0 || atom_cost(t) > atom_cost(best))) best = t;
+            int p = 0;
+            for (int q = 1; q < NP; ++q)
+                if (load[q] < load[p]) p = q;
+            done[best] = true;
+            where[best] = p;
+            load[p] += atom_cost(best);
+        }
+        for (int e = 0; e < N; ++e) {
+            const int p = where[atom_of(e)];
+            part[e] = static_cast<short>(p);
+            slot[e] = count[p];
+            entry[p][count[p]] = static_cast<short>(e);
+            ++count[p];
+        }
+    }
+    constexpr int max_count() const {
+        int m = 0;
+        for (int p = 0; p < NP; ++p) m = count[p] > m ? count[p] : m;
+        return m;
+    }
+};
+template <int PI, int NP>
+struct MomSplit {
+    static constexpr MomSplitTable<PI, NP> T{};
+};
+
 template <int MODEL, typename T>
 CBA_HD void mom_rows(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T vo, double* w) {
     constexpr int PI = IntrSize<MODEL>::value;
@@ -458,8 +533,8 @@ CBA_HD void mom_rows(const T* bc, const T* intr, const T* sd, T X, T Y, T uo, T 
         if (R::v_live(j)) w[n++] = Jvit[j];
 }
 
-// One observation's contribution to the entries e (e % NPARTS == PART, kept at acc[e / NPARTS]) of the moment row, from its
-// moment rows w and its target point (x, y).
+// One observation's contribution to the entries of the moment row that part PART keeps (MomSplitTable: entry e lives in
+// acc[slot[e]] of part[e]), from its moment rows w and its target point (x, y).
 template <int PI, int NPARTS, int PART>
 CBA_HD void mom_accumulate(const double* w, double x, double y, double* acc) {
     using L = MomLayout<PI>;
@@ -474,8 +549,9 @@ CBA_HD void mom_accumulate(const double* w, double x, double y, double* acc) {
     }
     const double m[3] = {1.0, x, y};
     const double mm[6] = {1.0, x, y, x * x, x * y, y * y};
-#define CBA_ACC(E, VALUE) if (((E) % NPARTS) == PART) acc[(E) / NPARTS] += (VALUE)
-#define CBA_FMA(E, A, B) if (((E) % NPARTS) == PART) acc[(E) / NPARTS] = __builtin_fma((A), (B), acc[(E) / NPARTS])
+    using S = MomSplit<PI, NPARTS>;
+#define CBA_ACC(E, VALUE) if (S::T.part[E] == PART) acc[S::T.slot[E]] += (VALUE)
+#define CBA_FMA(E, A, B) if (S::T.part[E] == PART) acc[S::T.slot[E]] = __builtin_fma((A), (B), acc[S::T.slot[E]])
     {   // Q = du du^T + dv dv^T and its six moments
         int kl = 0;
         for (int k = 0; k < 3; ++k)
