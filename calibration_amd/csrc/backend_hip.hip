@@ -269,22 +269,43 @@ __global__ __launch_bounds__(256) void k_backsub_wave(SchurDims d, int n_views, 
     }
 }
 
-// g_schur partial of one view chunk: out[g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k] (fixed order); run by the (chunk, pair 0)
-// workgroup of the syrk kernels so that the whole elimination result is one partial row per chunk and ONE k_row_sum
-__device__ __forceinline__ void schur_gvec_chunk(const SchurDims& d, int n_views, int nsh, int v0, const int32_t* __restrict__ view_cam_blk,
-                                                 const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ out) {
-    const int v1 = min(n_views, v0 + VCHUNK);
-    for (int g = threadIdx.x; g < nsh; g += blockDim.x) {
-        const int cam = g / d.PC, lc = g - cam * d.PC;  // (z_entry's decode, hoisted out of the view loop)
-        double s = 0.0;
-        for (int v = v0; v < v1; ++v) {
-            const int b = view_cam_blk[static_cast<int64_t>(v) * d.n_cams + cam];
-            if (b < 0) continue;
-            const double* z = blk_Z + static_cast<int64_t>(b) * 6 * d.PSH + lc;
-            for (int k = 0; k < 6; ++k) s += z[k * d.PSH] * y[6 * static_cast<int64_t>(v) + k];
-        }
-        out[g] = s;
+// Stage the 6 * VCHUNK rows of Z of one view chunk for the 64 columns from c0 (Zs[6 * (v - v0) + k][c]; zero past the shared block,
+// past the last view and where the view does not see the column's camera).  Two phases so that no load depends on another one:
+// the chunk's (view, camera) -> block table goes to LDS first, then every thread's Z entries are independent, unconditional
+// loads (the chain view -> block -> Z row, 24 times in sequence per thread, was most of the syrk kernels' time).
+constexpr int SYRK_MAX_CAMS = 64;
+__device__ __forceinline__ void stage_block_table(const SchurDims& d, int n_views, int v0, const int32_t* __restrict__ view_cam_blk, int* bsh) {
+    if (d.n_cams > SYRK_MAX_CAMS) return;  // (a rig of more than 64 cameras: stage_Z reads the table from global memory)
+    for (int t = threadIdx.x; t < VCHUNK * d.n_cams; t += blockDim.x) {
+        const int v = v0 + t / d.n_cams;
+        bsh[t] = v < n_views ? view_cam_blk[static_cast<int64_t>(v) * d.n_cams + t % d.n_cams] : -1;
     }
+}
+__device__ __forceinline__ void stage_Z(const SchurDims& d, const int* bsh, int n_views, int v0, const int32_t* __restrict__ view_cam_blk,
+                                        const double* __restrict__ blk_Z, int c0, int nsh, double (*Zs)[64]) {
+    const bool table = d.n_cams <= SYRK_MAX_CAMS;
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < 6 * VCHUNK * 64; idx += 256) {
+        const int row = idx >> 6, c = idx & 63, g = c0 + c;
+        const int gg = g < nsh ? g : 0;
+        const int cam = gg / d.PC, lc = gg - cam * d.PC;
+        const int v = v0 + row / 6;
+        const int b = table ? bsh[(row / 6) * d.n_cams + cam] : (v < n_views ? view_cam_blk[static_cast<int64_t>(v) * d.n_cams + cam] : -1);
+        const double z = blk_Z[(static_cast<int64_t>(b < 0 ? 0 : b) * 6 + row % 6) * d.PSH + lc];
+        Zs[row][c] = (g < nsh && b >= 0) ? z : 0.0;
+    }
+}
+
+// g_schur partial of one view chunk: out[g] = sum_{v in chunk} sum_k Z_v[k][g] y_v[k] (fixed (v, k) order), from the rows of Z the
+// syrk kernels have staged in LDS (Zs[6 * views + k][column - c0]) — read from global memory the chain view -> block index -> Z row
+// is two dependent loads per view and was most of the kernels' time.  Run by the DIAGONAL tile pair of a chunk for its 64
+// columns, so that the whole elimination result is one partial row per chunk and ONE k_row_sum.
+__device__ __forceinline__ void schur_gvec_chunk(const double (*Zs)[64], const double* ysh, int nrow, int c0, int nsh, double* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= 64 || c0 + c >= nsh) return;
+    double s = 0.0;
+    for (int r = 0; r < nrow; ++r) s += Zs[r][c] * ysh[r];
+    out[c0 + c] = s;
 }
 
 // grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
@@ -293,7 +314,11 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
                                                     const int32_t* __restrict__ view_cam_blk,
                                                     const double* __restrict__ blk_Z, const double* __restrict__ y,
                                                     double* __restrict__ partial) {
-    __shared__ double Zi[6][64], Zj[6][64];
+    // the chunk's 6 * VCHUNK rows of Z are staged in one go (one barrier per workgroup, not two per view: the staging of a
+    // 10-wide shared block is all latency); the products are added in the same (view, k) order as before
+    __shared__ double Zi[6 * VCHUNK][64], Zj[6 * VCHUNK][64];
+    __shared__ double ysh[6 * VCHUNK];
+    __shared__ int bsh[VCHUNK * SYRK_MAX_CAMS];
     // decode the upper-triangular tile pair
     int pair = blockIdx.y, ti = 0;
     while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
@@ -306,26 +331,22 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
     const int v0 = blockIdx.x * VCHUNK;
-    const int v1 = min(n_views, v0 + VCHUNK);
-    for (int v = v0; v < v1; ++v) {
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 768; idx += 256) {
-            const int which = idx / 384, rem = idx - which * 384;
-            const int k = rem >> 6, c = rem & 63;
-            const double val = z_entry(d, view_cam_blk, blk_Z, v, (which ? j0 : i0) + c, k, nsh);
-            if (which) Zj[k][c] = val; else Zi[k][c] = val;
-        }
-        __syncthreads();
+    const int nrow = 6 * (min(n_views, v0 + VCHUNK) - v0);
+    stage_block_table(d, n_views, v0, view_cam_blk, bsh);
+    __syncthreads();
+    stage_Z(d, bsh, n_views, v0, view_cam_blk, blk_Z, i0, nsh, Zi);
+    if (tj != ti) stage_Z(d, bsh, n_views, v0, view_cam_blk, blk_Z, j0, nsh, Zj);
+    if (static_cast<int>(threadIdx.x) < 6 * VCHUNK) ysh[threadIdx.x] = static_cast<int>(threadIdx.x) < nrow ? y[6 * static_cast<int64_t>(v0) + threadIdx.x] : 0.0;
+    __syncthreads();
+    const double (*Zc)[64] = tj != ti ? Zj : Zi;  // a diagonal tile: both factors are the same 64 columns, staged once
+    for (int r = 0; r < nrow; ++r) {
+        double a[4], b[4];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double a[4], b[4];
+        for (int q = 0; q < 4; ++q) { a[q] = Zi[r][ty * 4 + q]; b[q] = Zc[r][tx * 4 + q]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a[q] = Zi[k][ty * 4 + q]; b[q] = Zj[k][tx * 4 + q]; }
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
-        }
+            for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
     }
     double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
     double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
-    if (blockIdx.y == 0) schur_gvec_chunk(d, n_views, nsh, v0, view_cam_blk, blk_Z, y, row + static_cast<int64_t>(gridDim.y) * 4096);
+    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gridDim.y) * 4096);
 }
 
 // The same contraction on the matrix cores, used when the shared block is a real contraction (nsh >= 64: the 8-camera rig of
@@ -350,18 +371,20 @@ __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_view
                                                          const double* __restrict__ blk_Z, const double* __restrict__ y,
                                                          double* __restrict__ partial) {
     __shared__ double Zi[SYRK_ROWS][64], Zj[SYRK_ROWS][64];
+    __shared__ double ysh[SYRK_ROWS];
+    __shared__ int bsh[VCHUNK * SYRK_MAX_CAMS];
     int pair = blockIdx.y, ti = 0;
     while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
     const int tj = ti + pair;
     const int i0 = ti * 64, j0 = tj * 64;
     const int v0 = blockIdx.x * VCHUNK;
-    for (int idx = threadIdx.x; idx < 2 * SYRK_ROWS * 64; idx += 256) {
-        const int which = idx / (SYRK_ROWS * 64), rem = idx - which * (SYRK_ROWS * 64);
-        const int row = rem >> 6, c = rem & 63;
-        const int v = v0 + row / 6, k = row % 6;
-        const double val = v < n_views ? z_entry(d, view_cam_blk, blk_Z, v, (which ? j0 : i0) + c, k, nsh) : 0.0;
-        if (which) Zj[row][c] = val; else Zi[row][c] = val;
-    }
+    stage_block_table(d, n_views, v0, view_cam_blk, bsh);
+    __syncthreads();
+    stage_Z(d, bsh, n_views, v0, view_cam_blk, blk_Z, i0, nsh, Zi);
+    if (tj != ti) stage_Z(d, bsh, n_views, v0, view_cam_blk, blk_Z, j0, nsh, Zj);
+    const double (*Zc)[64] = tj != ti ? Zj : Zi;
+    const int nrow = 6 * (min(n_views, v0 + VCHUNK) - v0);
+    if (static_cast<int>(threadIdx.x) < SYRK_ROWS) ysh[threadIdx.x] = static_cast<int>(threadIdx.x) < nrow ? y[6 * static_cast<int64_t>(v0) + threadIdx.x] : 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_view
         const int r = 4 * step + lk;
         const double a = Zi[r][wave * 16 + li];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zj[r][c * 16 + li], acc[c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zc[r][c * 16 + li], acc[c], 0, 0, 0);
     }
     double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
     double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_view
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) out[(wave * 16 + lk + 4 * reg) * 64 + c * 16 + li] = acc[c][reg];
-    if (blockIdx.y == 0) schur_gvec_chunk(d, n_views, nsh, v0, view_cam_blk, blk_Z, y, row + static_cast<int64_t>(gridDim.y) * 4096);
+    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gridDim.y) * 4096);
 }
 
 __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
