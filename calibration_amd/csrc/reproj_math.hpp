@@ -449,7 +449,7 @@ struct MomRows {
 // out round-robin (entry e to part e mod NP, the first form of this kernel) made every part form nearly all of those products:
 // 380 accumulate instructions per observation over the four parts where 276 suffice.  Here whole families go to one part
 // (Em by k, Qm, qm, gradient + |r|^2; the rows of the intrinsics block, which share nothing, fill the parts up), assigned
-// largest-first to the least loaded part by instruction count.  NP = 1 gives the identity.
+// largest-first to the least loaded part (by instruction count) that has room for it.  NP = 1 gives the identity.
 template <int PI, int NP>
 struct MomSplitTable {
     static constexpr int N = MomLayout<PI>::N, NATOM = 6 + PI;
@@ -475,6 +475,8 @@ struct MomSplitTable {
         for (int b = a; b < PI; ++b) c += (hu(a) && hu(b) ? 1 : 0) + (hv(a) && hv(b) ? 1 : 0);
         return c;
     }
+    static constexpr int CAP = (N + NP - 1) / NP + 1;
+    static constexpr int atom_size(int t) { return t < 3 ? 3 * PI : (t == 3 ? 36 : (t == 4 ? 9 : (t == 5 ? PI + 1 : PI - (t - 6)))); }
     static constexpr int atom_of(int e) {
         using L = MomLayout<PI>;
         if (e < L::OFF_q) return 3;
@@ -486,15 +488,23 @@ struct MomSplitTable {
         return 6 + a;
     }
     constexpr MomSplitTable() : part(), slot(), count(), entry() {
-        int load[NP] = {}, where[NATOM] = {};
+        int load[NP] = {}, fill[NP] = {}, where[NATOM] = {};
         bool done[NATOM] = {};
         for (int n = 0; n < NATOM; ++n) {
             int best = -1;
             for (int t = 0; t < NATOM; ++t)
                 if (!done[t] && (best < 0 || atom_cost(t) > atom_cost(best))) best = t;
-            int p = 0;
-            for (int q = 1; q < NP; ++q)
-                if (load[q] < load[p]) p = q;
+            // least loaded part among those with room: the accumulator count of a part is capped one above the even share (the
+            // part with the most accumulators sets the kernel's register count)
+            int p = -1;
+            for (int q = 0; q < NP; ++q)
+                if (fill[q] + atom_size(best) <= CAP && (p < 0 || load[q] < load[p])) p = q;
+            if (p < 0) {
+                p = 0;
+                for (int q = 1; q < NP; ++q)
+                    if (load[q] < load[p]) p = q;
+            }
+            fill[p] += atom_size(best);
             done[best] = true;
             where[best] = p;
             load[p] += atom_cost(best);
