@@ -45,24 +45,26 @@ __global__ __launch_bounds__(256) void k_weights_cost(int n_blocks, int NACC, in
                                                       double* __restrict__ out) {
     __shared__ double sh[2][256];
     double c = 0.0, ss = 0.0;
-    // four independent loads in flight per thread (each is a cache line of its own: one block's |r|^2), summed in the same order
-    for (int b0 = static_cast<int>(threadIdx.x); b0 < n_blocks; b0 += 4 * 256) {
-        double sv[4];
+    // up to 16 independent loads in flight per thread (each is a cache line of its own: one block's |r|^2), summed in the same order
+    constexpr int NQ = 16;
+    for (int b0 = static_cast<int>(threadIdx.x); b0 < n_blocks; b0 += NQ * 256) {
+        double sv[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int b = b0 + q * 256;
             sv[q] = b < n_blocks ? blk_acc[static_cast<int64_t>(b) * NACC + s_idx] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int b = b0 + q * 256;
-            if (b >= n_blocks) break;
-            double rho, w;
-            huber(sv[q], huber_delta, &rho, &w);
-            blk_w[b] = w;
-            blk_s[b] = sv[q];
-            c += 0.5 * rho;
-            ss += sv[q];
+            if (b < n_blocks) {
+                double rho, w;
+                huber(sv[q], huber_delta, &rho, &w);
+                blk_w[b] = w;
+                blk_s[b] = sv[q];
+                c += 0.5 * rho;
+                ss += sv[q];
+            }
         }
     }
     sh[0][threadIdx.x] = c;
@@ -86,17 +88,17 @@ __global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, c
     const int64_t p0 = chunk_off[k], p1 = chunk_off[k + 1];
     for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
         double s = 0.0;
-        for (int64_t p = p0; p < p1; p += 4) {  // four block rows in flight, added in list order
-            double a[4], w[4];
+        for (int64_t p = p0; p < p1; p += CCHUNK) {  // the chunk's block rows in flight together, added in list order
+            double a[CCHUNK], w[CCHUNK];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CCHUNK; ++q) {
                 const bool in = p + q < p1;
                 const int b = in ? cam_blk[p + q] : 0;
                 w[q] = in ? blk_w[b] : 0.0;
                 a[q] = in ? blk_acc[static_cast<int64_t>(b) * NACC + e] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < CCHUNK; ++q)
                 if (p + q < p1) s += w[q] * a[q];
         }
         partial[static_cast<int64_t>(k) * NACC + e] = s;
