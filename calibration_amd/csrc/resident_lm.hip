@@ -714,11 +714,13 @@ bool resident_lm_eligible(const Engine& e, const cba_options& o) {
     if (s.n_blocks == 0 || s.nsh > RES_NSH_MAX || s.n_cams > RES_MAX_CAMS) return false;
     if (st->resident_mode == 1) {
         if (st->resident_max_obs >= 0) return s.n_obs <= st->resident_max_obs;  // CBA_LM_RESIDENT_MAX_OBS
-        // Measured crossover with the host-driven iteration (tools/exp_resident.py, one MI355X): per LM step the resident
-        // kernel costs ~45 + 1.0 n_views + 0.0105 n_obs us on the intrinsic chain against ~108 + 0.003 n_obs host-driven;
-        // the two-pose chains need six register passes over 276-325 sums on ONE CU and only win on tiny problems.
-        if (s.chain == CBA_CHAIN_INTRINSIC) return 1.0 * s.n_views + 0.0075 * static_cast<double>(s.n_obs) <= 63.0;
-        return s.n_obs <= (s.chain == CBA_CHAIN_EXTRINSIC ? 1024 : 768);
+        // Measured crossover with the host-driven iteration (tools/exp_resident.py, one MI355X, end of round 2): per LM step the
+        // resident kernel costs ~38 + 1.2 n_views + 0.0105 n_obs us on the intrinsic chain against ~86 us host-driven (flat up to
+        // 4e4 observations; 108 + 0.003 n_obs before the step's kernels and its wait were trimmed).  The two-pose chains need six
+        // register passes over 276-325 sums on ONE CU: 109 us per step at 200 observations against 91 (EXTRINSIC), 88 against 72
+        // at 360 (BUNDLE) - the host-driven iteration wins at every size measured, so the automatic mode leaves them to it.
+        if (s.chain == CBA_CHAIN_INTRINSIC) return 1.2 * s.n_views + 0.0105 * static_cast<double>(s.n_obs) <= 48.0;
+        return false;
     }
     return true;
 }

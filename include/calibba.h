@@ -225,10 +225,10 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
 /* How cba_reproj_solve runs the iteration.  0: host-driven (every stage a kernel launch, the accept / reject loop on the host;
  * the only form for multi-rank handles, verbose solves and the fp32 study).  2: "resident" — the whole solve in ONE launch of a
  * single-workgroup kernel, for problems too small to fill the chip (the sizes the reference's own tests and pipelines run:
- * the host-driven iteration costs ~0.2 ms per LM step however little work it carries); falls back to 0 when the kernel cannot
+ * the host-driven iteration costs ~0.09 ms per LM step however little work it carries); falls back to 0 when the kernel cannot
  * take the problem (reduced system wider than 80, > 16 cameras).  1 (default): resident below the measured crossover with
- * the host-driven form (intrinsic chain: n_views + 0.0075 n_obs <= 63, e.g. 20 views x 280 points; extrinsic <= 1024 and
- * bundle <= 768 observations).
+ * the host-driven form (intrinsic chain: 1.2 n_views + 0.0105 n_obs <= 48, e.g. 20 views x 88 points; the host-driven
+ * iteration runs a step in ~86 us and wins on the two-pose chains at every size).
  * Both forms follow the same rules and agree to rounding. */
 cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
 

@@ -8,7 +8,8 @@ import numpy as np
 from calibration_amd import optim, synth, capi
 
 CASES = [("intr", 10, 8, 11), ("intr", 20, 8, 11), ("intr", 50, 8, 11), ("intr", 20, 15, 15), ("intr", 20, 20, 20), ("intr", 50, 20, 20),
-         ("intr", 100, 20, 20), ("ext", 10, 8, 11), ("bundle", 25, 8, 11)]
+         ("intr", 100, 20, 20), ("ext", 10, 8, 11), ("bundle", 25, 8, 11), ("ext", 4, 5, 5), ("ext", 8, 6, 6), ("ext", 6, 8, 11), ("bundle", 10, 6, 6),
+         ("bundle", 6, 8, 11), ("bundle", 12, 8, 11), ("intr", 30, 8, 11), ("intr", 10, 12, 12), ("intr", 6, 20, 20)]
 o = capi.default_options(); o.compute_covariance = 0
 print(f"{'case':28s} {'obs':>7s} {'iters':>5s} {'host ms':>9s} {'resident ms':>11s} {'us/iter host':>12s} {'us/iter res':>11s}")
 for kind, nv, rows, cols in CASES:
