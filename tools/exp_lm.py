@@ -21,6 +21,10 @@ for w in which:
         sc = synth.scene_extrinsics_shard(1000, 0, 1000)
     elif w == "c3e":  # the share of ONE rank when C3 is split over 8 GPUs (500 of the 4000 views): what a rank computes per step, without the exchange
         sc = synth.scene_extrinsics_shard(4000, 0, 500)
+    elif w == "c3r2":  # ... over 2 GPUs (2000 views)
+        sc = synth.scene_extrinsics_shard(4000, 0, 2000)
+    elif w == "c3r4":  # ... over 4 GPUs (1000 views)
+        sc = synth.scene_extrinsics_shard(4000, 0, 1000)
     elif w == "c1h":
         os.environ["CBA_LM_RESIDENT"] = "0"
         sc = synth.scene_intrinsics(20, noise_px=0.2)
