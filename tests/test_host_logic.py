@@ -982,3 +982,70 @@ def test_dense_cholesky_blocked_and_scalar_forms_solve_the_same_systems():
         out = subprocess.run([exe, str(n), "x"], input=" ".join(repr(float(v)) for v in np.concatenate([A.ravel(), np.zeros(n)])), check=True,
                              capture_output=True, text=True).stdout
         assert out.strip() == "refused"
+
+
+def test_moment_split_table_is_a_partition_with_balanced_parts():
+    """MomSplitTable (reproj_math.hpp): which wavefront of a Mode B workgroup keeps which moment.  For both intrinsics sizes and
+    1-5 parts: every entry belongs to exactly one (part, slot), entry[] inverts (part, slot), no part holds more than
+    ceil(N / NP) + 1 accumulators, families that share products stay together (the 3 PI entries of Em with the same k, the 36 of
+    Qm, the 9 of qm), the instruction loads of the parts differ by less than a fifth, and one part is the identity."""
+    import subprocess, tempfile, textwrap
+
+    src = textwrap.dedent("""
+        #include <cstdio>
+        #include "reproj_math.hpp"
+        using namespace cba;
+        template <int PI, int NP> void dump() {
+            constexpr MomSplitTable<PI, NP> T{};
+            using L = MomLayout<PI>;
+            std::printf("%d %d %d", PI, NP, L::N);
+            for (int e = 0; e < L::N; ++e) std::printf(" %d %d", T.part[e], T.slot[e]);
+            for (int p = 0; p < NP; ++p) {
+                std::printf(" %d", T.count[p]);
+                for (int l = 0; l < T.count[p]; ++l) std::printf(" %d", T.entry[p][l]);
+            }
+            int load[NP] = {};
+            for (int t = 0; t < MomSplitTable<PI, NP>::NATOM; ++t) {
+                int e0 = 0;  // first entry of atom t
+                while (MomSplitTable<PI, NP>::atom_of(e0) != t) ++e0;
+                load[T.part[e0]] += MomSplitTable<PI, NP>::atom_cost(t);
+            }
+            for (int p = 0; p < NP; ++p) std::printf(" %d", load[p]);
+            std::putchar(10);
+        }
+        int main() {
+            dump<10, 1>(); dump<10, 2>(); dump<10, 3>(); dump<10, 4>(); dump<10, 5>();
+            dump<12, 1>(); dump<12, 3>(); dump<12, 4>(); dump<12, 5>();
+            return 0;
+        }""")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.cpp"), "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "calibration_amd", "csrc"), "-I" + os.path.join(root, "include"),
+                        os.path.join(td, "t.cpp"), "-o", exe], check=True)
+        lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert len(lines) == 9
+    for line in lines:
+        v = [int(x) for x in line.split()]
+        pi, npart, n = v[:3]
+        ps = np.array(v[3:3 + 2 * n]).reshape(n, 2)
+        rest = v[3 + 2 * n:]
+        seen = set()
+        for p in range(npart):
+            cnt, rest = rest[0], rest[1:]
+            ent, rest = rest[:cnt], rest[cnt:]
+            assert cnt <= -(-n // npart) + 1, (pi, npart, cnt)
+            for l, e in enumerate(ent):
+                assert (ps[e, 0], ps[e, 1]) == (p, l)
+                seen.add(e)
+        assert seen == set(range(n))
+        loads = rest
+        assert len(loads) == npart and max(loads) - min(loads) <= 0.2 * max(loads), (pi, npart, loads)
+        if npart == 1:
+            assert np.array_equal(ps[:, 1], np.arange(n))
+        off_e = 45
+        for k in range(3):  # Em, fixed k: one part
+            fam = [off_e + (a * 3 + k) * pi + j for a in range(3) for j in range(pi)]
+            assert len({ps[e, 0] for e in fam}) == 1
+        assert len({ps[e, 0] for e in range(36)}) == 1 and len({ps[e, 0] for e in range(36, 45)}) == 1
