@@ -306,6 +306,8 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
         e.blk_tile_off[d.n_blocks] = static_cast<int64_t>(tb.size());
         e.n_tilesA = static_cast<int64_t>(ta.size());
         e.n_tilesB = static_cast<int64_t>(tb.size());
+        e.max_tileB = 0;
+        for (const Tile& t : tb) e.max_tileB = std::max(e.max_tileB, t.count);
         e.tilesA.alloc(ta.size()); e.tilesA.upload(ta.data(), ta.size(), e.stream);
         e.tilesB.alloc(tb.size()); e.tilesB.upload(tb.data(), tb.size(), e.stream);
         e.d_blk_tile_off.alloc(e.blk_tile_off.size());

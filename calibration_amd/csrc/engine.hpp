@@ -172,6 +172,7 @@ struct Engine {
     std::vector<int32_t> blk_cam, blk_view;
     std::vector<int64_t> blk_tile_off;  // Mode B tiles per block CSR (host)
     int64_t n_tilesA = 0, n_tilesB = 0;
+    int32_t max_tileB = 0;  // observations of the largest Mode B tile (small-block problems take the single-group kernel)
 
     // host copies of the parameters (current accepted state); h_cam / h_target are always sized
     // (7 per camera / 7) and simply unused by chains that have no such block

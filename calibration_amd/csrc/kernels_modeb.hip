@@ -64,7 +64,10 @@ template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW 
 
 // the work of wavefront PART of the workgroup
 // ABL (timing-only ablations, WRONG results): 1 = no barriers, 2 = no LDS reads (the own rows are accumulated NP times), 3 = both
-template <class FORM, int PART, int NBUF, typename T, int ABL = 0>
+// ONE: every tile of the problem fits ONE group (<= 64 NP observations: the 88-point views of a hand-eye bundle) - no group loop,
+// no prefetch of a next group, no second barrier; the registers that frees let a third workgroup live on the CU, and with
+// thousands of one-group tiles the kernel is a latency chain per workgroup whose throughput is the number of workgroups in flight.
+template <class FORM, int PART, int NBUF, typename T, int ABL = 0, bool ONE = false>
 __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
                                                const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out) {
     constexpr int NP = FORM::NPARTS, NROW = FORM::NROW, NR2 = ShareDims<FORM>::NR2;
@@ -72,7 +75,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
     double acc[NPAD];
 #pragma unroll
     for (int e = 0; e < NPAD; ++e) acc[e] = 0.0;
-    const int n_groups = (t.count + 64 * NP - 1) / (64 * NP);  // the same for every wavefront of the workgroup
+    const int n_groups = ONE ? 1 : (t.count + 64 * NP - 1) / (64 * NP);  // the same for every wavefront of the workgroup
     T xc = T(0), yc = T(0), uc = T(0), vc = T(0);
     {
         const int j = PART * 64 + lane;
@@ -84,7 +87,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
         const int j = (g * NP + PART) * 64 + lane;
         v2f64 (*sh)[NR2][64] = shb + (NBUF == 2 ? (g & 1) * NP : 0);
         T xn = T(0), yn = T(0), un = T(0), vn = T(0);
-        if (j + 64 * NP < t.count) {  // the loads of the next group's own chunk, before this group's arithmetic
+        if (!ONE && j + 64 * NP < t.count) {  // the loads of the next group's own chunk, before this group's arithmetic
             const int64_t i = t.start + j + 64 * NP, k2 = t.xy_start + j + 64 * NP;
             xn = X[k2]; yn = Y[k2]; un = u[i]; vn = v[i];
         }
@@ -110,7 +113,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
                 FORM::template accumulate<PART>(w, xo, yo, acc);
             }
         }
-        if (NBUF == 1 && !(ABL & 1)) __syncthreads();  // before the next group overwrites the rows
+        if (NBUF == 1 && !(ABL & 1) && !ONE) __syncthreads();  // before the next group overwrites the rows
         xc = xn; yc = yn; uc = un; vc = vn;
     }
     bool owner;
@@ -126,7 +129,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 }
 
 // one workgroup of FORM::NPARTS wavefronts per tile
-template <class FORM, int NBUF, typename T, int ABL = 0>
+template <class FORM, int NBUF, typename T, int ABL = 0, bool ONE = false>
 __global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
@@ -143,18 +146,23 @@ __global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __r
     const T* ip = intr + static_cast<int64_t>(cam) * PI;
     const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double* out = partial + w * FORM::NTOT;
-    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
-    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------
 template <class FORM, int NBUF, typename T>
 static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
-    hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
-                       e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+    static const bool one_ok = !(std::getenv("CBA_MODEB_ONEGROUP") && std::atoi(std::getenv("CBA_MODEB_ONEGROUP")) == 0);
+    if (NBUF == 1 && one_ok && e.max_tileB <= 64 * FORM::NPARTS)  // every tile is one group: the single-group kernel
+        hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream,
+                           e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+    else
+        hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
+                           e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
 }
 
 template <class F64, class F32, int NBUF = 1>
