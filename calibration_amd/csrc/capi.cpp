@@ -493,63 +493,44 @@ cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, 
 
 int64_t cba_reproj_num_observations(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->n_obs : 0; }
 
+// The Mode A output block.  Where the driver puts a multi-GB buffer decides whether k_eval streams into it at 6.2 or at 6.5 TB/s:
+// a property of the allocation, stable over its lifetime (tools/exp_placement2.py: six handles of the same problem in one process
+// 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again on re-measurement; shifting the output window inside a block by 256 B ... 64 MiB
+// changes nothing) - the pages of a plain hipMalloc are scattered over the stacks differently every time.  A physically
+// CONTIGUOUS block (hipExtMallocWithFlags, hipDeviceMallocContiguous) gets the interleaving the memory system was laid out for:
+// 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Falls back to the plain allocation when the runtime cannot find a
+// contiguous range (CBA_EVAL_CONTIGUOUS=0: always plain).
+}  // extern "C"
+template <typename T>
+static void alloc_output(DevBuf<T>& b, size_t count) {
+    static const bool contiguous = [] { const char* v = getenv("CBA_EVAL_CONTIGUOUS"); return !(v && atoi(v) == 0); }();
+    const size_t bytes = count * sizeof(T);
+    if (contiguous && bytes >= (size_t(64) << 20)) {
+        void* p = nullptr;
+        if (b.p && b.owned) (void)hipDeviceSynchronize();
+        b.release();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            b.p = static_cast<T*>(p);
+            b.n = count;
+            b.granted = bytes;  // above the block cache's limit: goes back to the runtime with hipFree
+            CBA_HIP(hipGetDevice(&b.device));
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    b.alloc(count);
+}
+extern "C" {
+
 static void ensure_eval_buffers(Engine& e) {
     if (e.scalar) {
         const size_t jn = static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A;
-        if (e.Jf.n < jn) e.Jf.alloc(jn);
+        if (e.Jf.n < jn) alloc_output(e.Jf, jn);
         return;
     }
     if (!e.eval_blocked && e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
     const size_t jn = e.eval_blocked ? static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A : static_cast<size_t>(2 * e.PL) * e.ld;
-    if (e.J.n >= jn) return;
-    e.J.alloc(jn);
-    // Placement probe, an experiment knob (CBA_EVAL_PLACEMENT=<candidates>; default 1 = off).  Where the driver puts a multi-GB
-    // output buffer decides whether k_eval streams into it at 6.2 or at 6.5 TB/s: a property of the allocation, stable over its
-    // lifetime (tools/exp_placement2.py: six handles of the same problem in one process 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again
-    // on re-measurement) - that, not the box, is the 0.77 ... 0.81 spread of the headline figure.  With the knob the kernel itself
-    // is timed on up to `candidates` buffers when an output of 256 MB ... 8 GB is first allocated (one warm-up launch + two timed)
-    // and the fastest is kept; the search stops once it holds a buffer 3 % faster than the slowest it has seen.  Rejected candidates
-    // stay allocated until the end - that is what makes the next one land elsewhere - and are only taken while they leave 8 GB of
-    // the device free.  On one box this put 12 of 12 handles at 6.5 TB/s (6 of 12 without); on two others fast placements were
-    // rare (1 in 6 ... 10) and 4 ... 8 candidates found none for 4 ... 9 ms of first-evaluation time: not reliable enough to be
-    // the default.
-    static const int candidates = [] { const char* v = getenv("CBA_EVAL_PLACEMENT"); return v ? atoi(v) : 1; }();
-    const size_t bytes = jn * sizeof(double);
-    if (candidates <= 1 || bytes < (size_t(256) << 20) || bytes > (size_t(8) << 30) || !e.eval_blocked) return;
-    auto time_eval = [&] {
-        launch_eval(e);
-        CBA_HIP(hipEventRecord(e.ev0, e.stream));
-        launch_eval(e);
-        launch_eval(e);
-        CBA_HIP(hipEventRecord(e.ev1, e.stream));
-        CBA_HIP(hipEventSynchronize(e.ev1));
-        float ms = 0.f;
-        CBA_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
-        return ms;
-    };
-    auto swap_buf = [](DevBuf<double>& a, DevBuf<double>& b) {
-        std::swap(a.p, b.p); std::swap(a.n, b.n); std::swap(a.granted, b.granted); std::swap(a.device, b.device);
-    };
-    launch_block_consts(e, 0);
-    float best = time_eval(), worst = best;
-    std::vector<DevBuf<double>> rejected(static_cast<size_t>(candidates - 1));
-    for (int k = 0; k + 1 < candidates && best > 0.97f * worst; ++k) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t(8) << 30)) break;
-        DevBuf<double>& c = rejected[static_cast<size_t>(k)];
-        try {
-            c.alloc(jn);
-        } catch (const std::exception&) {
-            (void)hipGetLastError();
-            break;
-        }
-        swap_buf(c, e.J);  // e.J = the new candidate, c = the best so far
-        const float ms = time_eval();
-        worst = std::max(worst, ms);
-        if (ms < best) best = ms;     // keep the candidate; the previous best (in c) is released below
-        else swap_buf(c, e.J);        // keep the previous best
-    }
-    CBA_HIP(hipStreamSynchronize(e.stream));
+    if (e.J.n < jn) alloc_output(e.J, jn);
 }
 
 cba_status cba_reproj_eval(cba_reproj* h) {
