@@ -363,6 +363,33 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     pt.lap("warm-up pass");
 }
 
+// The Mode A output block.  Where the driver puts a multi-GB buffer decides whether k_eval streams into it at 6.2 or at 6.5 TB/s:
+// a property of the allocation, stable over its lifetime (tools/exp_placement2.py: six handles of the same problem in one process
+// 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again on re-measurement; shifting the output window inside a block by 256 B ... 64 MiB
+// changes nothing) - the pages of a plain hipMalloc are scattered over the stacks differently every time.  A physically
+// CONTIGUOUS block (hipExtMallocWithFlags, hipDeviceMallocContiguous) gets the interleaving the memory system was laid out for:
+// 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Falls back to the plain allocation when the runtime cannot find a
+// contiguous range (CBA_EVAL_CONTIGUOUS=0: always plain).
+template <typename T>
+static void alloc_output(DevBuf<T>& b, size_t count) {
+    static const bool contiguous = [] { const char* v = getenv("CBA_EVAL_CONTIGUOUS"); return !(v && atoi(v) == 0); }();
+    const size_t bytes = count * sizeof(T);
+    if (contiguous && bytes >= (size_t(64) << 20)) {
+        void* p = nullptr;
+        if (b.p && b.owned) (void)hipDeviceSynchronize();
+        b.release();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            b.p = static_cast<T*>(p);
+            b.n = count;
+            b.granted = bytes;  // above the block cache's limit: goes back to the runtime with hipFree
+            CBA_HIP(hipGetDevice(&b.device));
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    b.alloc(count);
+}
+
 extern "C" {
 
 const char* cba_version(void) { return CBA_VERSION_STRING; }
@@ -492,35 +519,6 @@ cba_status cba_reproj_get_params(cba_reproj* h, double* intr, double* cam_pose, 
 }
 
 int64_t cba_reproj_num_observations(const cba_reproj* h) { return h ? reinterpret_cast<const Engine*>(h)->n_obs : 0; }
-
-// The Mode A output block.  Where the driver puts a multi-GB buffer decides whether k_eval streams into it at 6.2 or at 6.5 TB/s:
-// a property of the allocation, stable over its lifetime (tools/exp_placement2.py: six handles of the same problem in one process
-// 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again on re-measurement; shifting the output window inside a block by 256 B ... 64 MiB
-// changes nothing) - the pages of a plain hipMalloc are scattered over the stacks differently every time.  A physically
-// CONTIGUOUS block (hipExtMallocWithFlags, hipDeviceMallocContiguous) gets the interleaving the memory system was laid out for:
-// 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Falls back to the plain allocation when the runtime cannot find a
-// contiguous range (CBA_EVAL_CONTIGUOUS=0: always plain).
-}  // extern "C"
-template <typename T>
-static void alloc_output(DevBuf<T>& b, size_t count) {
-    static const bool contiguous = [] { const char* v = getenv("CBA_EVAL_CONTIGUOUS"); return !(v && atoi(v) == 0); }();
-    const size_t bytes = count * sizeof(T);
-    if (contiguous && bytes >= (size_t(64) << 20)) {
-        void* p = nullptr;
-        if (b.p && b.owned) (void)hipDeviceSynchronize();
-        b.release();
-        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
-            b.p = static_cast<T*>(p);
-            b.n = count;
-            b.granted = bytes;  // above the block cache's limit: goes back to the runtime with hipFree
-            CBA_HIP(hipGetDevice(&b.device));
-            return;
-        }
-        (void)hipGetLastError();
-    }
-    b.alloc(count);
-}
-extern "C" {
 
 static void ensure_eval_buffers(Engine& e) {
     if (e.scalar) {
