@@ -368,13 +368,15 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
 // 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again on re-measurement; shifting the output window inside a block by 256 B ... 64 MiB
 // changes nothing) - the pages of a plain hipMalloc are scattered over the stacks differently every time.  A physically
 // CONTIGUOUS block (hipExtMallocWithFlags, hipDeviceMallocContiguous) gets the interleaving the memory system was laid out for:
-// 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Falls back to the plain allocation when the runtime cannot find a
-// contiguous range (CBA_EVAL_CONTIGUOUS=0: always plain).
+// 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Up to 4 GiB only: such a block comes back in a millisecond, a larger
+// one costs ~31 ms per GiB (tools/exp_first_eval_c3.py: 6.9 GiB 0.21 s, 59 GB 1.7 s on the first evaluation) for the +0.4 ... 2 %
+// it gains at those sizes.  Falls back to the plain allocation when the runtime cannot find a contiguous range
+// (CBA_EVAL_CONTIGUOUS=0: always plain).
 template <typename T>
 static void alloc_output(DevBuf<T>& b, size_t count) {
     static const bool contiguous = [] { const char* v = getenv("CBA_EVAL_CONTIGUOUS"); return !(v && atoi(v) == 0); }();
     const size_t bytes = count * sizeof(T);
-    if (contiguous && bytes >= (size_t(64) << 20)) {
+    if (contiguous && bytes >= (size_t(64) << 20) && bytes <= (size_t(4) << 30)) {
         void* p = nullptr;
         if (b.p && b.owned) (void)hipDeviceSynchronize();
         b.release();
