@@ -12,6 +12,7 @@
 // bitwise reproducible and 1/2/4/8-rank runs differ only by the all-reduce's own rounding.
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -25,6 +26,7 @@
 namespace cba {
 
 constexpr int VCHUNK = 8;    // views per syrk / gvec workgroup
+constexpr size_t CTL_REC_FETCH = CS_COUNT + 80;  // HipLMState::ctl_rec = [control record | staged scalars + lmp (72) | fetched parameters]
 constexpr int CCHUNK = 16;   // blocks per camera-sum chunk
 
 __global__ void k_weights(int n_blocks, int NACC, int s_idx, const double* __restrict__ blk_acc, double huber_delta,
@@ -446,16 +448,17 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const double* __restri
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t nn = static_cast<int64_t>(a.n) * a.n;
     const int64_t sw = static_cast<int64_t>(a.n_tiles) * (a.n_tiles + 1) / 2 * 4096;
-    if (tid < nn) {
+    if (tid < nn) {  // S travels as its upper triangle, packed row-major (PackLayout)
         const int i = static_cast<int>(tid / a.n), j = static_cast<int>(tid % a.n);
-        double val = 0.0;
-        if (a.has_schur) {
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            const int ti = lo >> 6, tj = hi >> 6;
-            const int pair = ti * a.n_tiles - ti * (ti - 1) / 2 + (tj - ti);  // upper-triangular tile pairs in (ti, tj >= ti) order
-            val = tiles[static_cast<int64_t>(pair) * 4096 + (lo & 63) * 64 + (hi & 63)];
+        if (i <= j) {
+            double val = 0.0;
+            if (a.has_schur) {
+                const int ti = i >> 6, tj = j >> 6;
+                const int pair = ti * a.n_tiles - ti * (ti - 1) / 2 + (tj - ti);  // upper-triangular tile pairs in (ti, tj >= ti) order
+                val = tiles[static_cast<int64_t>(pair) * 4096 + (i & 63) * 64 + (j & 63)];
+            }
+            pack[a.off_S + ctl_sidx(a.n, i, j)] = val;
         }
-        pack[a.off_S + tid] = val;
     }
     if (tid < a.n) pack[a.off_g + tid] = a.has_schur ? tiles[sw + tid] : 0.0;
     if (tid < a.n_ranks) pack[a.off_gmax + tid] = (a.has_schur && tid == a.rank) ? tiles[sw + a.n] : 0.0;
@@ -509,7 +512,9 @@ static inline unsigned nblk(int64_t n, int per) { return static_cast<unsigned>(s
 struct HipBackend final : Backend {
     Engine& e;
     HipLMState& st;
-    explicit HipBackend(Engine& eng, HipLMState& s) : e(eng), st(s) { st.current_is_on_device = false; }
+    const double* lmp_src;  // [radius, init_scale] as the elimination kernels read it: page-locked host memory written by the host-side
+                            // form of the iteration, or the controller's device copy
+    explicit HipBackend(Engine& eng, HipLMState& s) : e(eng), st(s), lmp_src(s.pin_lmp.p) { st.current_is_on_device = false; }
 
     void set_view_fixed(const std::vector<int32_t>& f) override {
         if (!f.empty()) e.view_fixed.upload(f.data(), f.size(), e.stream);
@@ -628,12 +633,12 @@ struct HipBackend final : Backend {
         const int n = s.nsh;
         if (st.schur_wave)
             hipLaunchKernelGGL(k_schur_view_wave, dim3(nblk(s.n_views, 4)), dim3(256), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
+                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, lmp_src, constrained ? 1 : 0,
                                e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                                st.view_gmax.p);
         else
             hipLaunchKernelGGL(k_schur_view, dim3(nblk(s.n_views, 64)), dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, st.pin_lmp.p, constrained ? 1 : 0,
+                               st.link_blk.p, e.blk_acc.p, e.blk_w.p, e.view_fixed.p, lmp_src, constrained ? 1 : 0,
                                e.view[which].p, e.view_scale2.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.blk_Z.p,
                                st.view_gmax.p);
         const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
@@ -722,16 +727,16 @@ struct HipBackend final : Backend {
         }
         st.pin_packed.reserve(static_cast<size_t>(L.size));
     }
-    // Where the pack is assembled: in device memory when RCCL reduces it there in place; otherwise the kernels write it straight
-    // into page-locked host memory (no copy command before the one synchronisation, as the unpacked stages do).
-    double* pack_target() { return e.rccl_comm ? st.pack_dev.p : st.pin_packed.p; }
+    // Where the pack is assembled: in device memory, where RCCL reduces it in place and the controller (lm_ctl.hip) reads it;
+    // with a host-callback transport (gloo / MPI) the kernels write it straight into page-locked host memory instead.
+    bool host_transport() const { return !e.rccl_comm && e.allreduce != nullptr; }
+    double* pack_target() { return host_transport() ? st.pin_packed.p : st.pack_dev.p; }
     void enqueue_pack(const PackLayout& L, bool has_blocks, bool has_schur, int has_stats, int has_cost = -1) {
         const int64_t work = std::max<int64_t>({static_cast<int64_t>(st.s.nsh) * st.s.nsh, static_cast<int64_t>(st.s.n_cams) * st.s.NACC, L.n_ranks, 1});
         hipLaunchKernelGGL(k_pack, dim3(nblk(work, 256)), dim3(256), 0, e.stream, pack_args(L, has_blocks, has_schur, has_stats, has_cost),
                            st.stat_dev.p, st.sys_tiles.p, pack_target());
         CBA_HIP(hipGetLastError());
     }
-    // sum [off, off + count) of the packed buffer over the ranks and bring it to `pack` on the host
     void wait_step() {
         if (!st.sync_spin) { CBA_HIP(hipStreamSynchronize(e.stream)); return; }
         if (!st.step_done) CBA_HIP(hipEventCreateWithFlags(&st.step_done, hipEventDisableTiming));
@@ -741,24 +746,39 @@ struct HipBackend final : Backend {
             const hipError_t q = hipEventQuery(st.step_done);
             if (q == hipSuccess) return;
             if (q != hipErrorNotReady) CBA_HIP(q);
+#if defined(__x86_64__)
             __builtin_ia32_pause();
+#endif
             // a long stage (Mode B over 1e7+ observations) gains nothing from polling: sleep after 300 us
             if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
         }
         CBA_HIP(hipStreamSynchronize(e.stream));
     }
-    void exchange(int64_t off, int64_t count, const AllReduce& ar, double* pack) {
+    // Sum [off, off + count) of the packed buffer over the ranks.  host_out != nullptr: the reduced range is also brought to the
+    // host (the host-side form of the iteration, line-search samples); to_device: with a host transport the reduced range goes
+    // back up for the controller.
+    void exchange(int64_t off, int64_t count, const AllReduce& ar, double* host_out, bool to_device = false) {
         if (e.rccl_comm) {  // RCCL over xGMI, in place on the device buffer, on the engine's stream: no host staging
             const ncclResult_t r = ncclAllReduce(st.pack_dev.p + off, st.pack_dev.p + off, static_cast<size_t>(count), ncclDouble, ncclSum,
                                                  reinterpret_cast<ncclComm_t>(e.rccl_comm), e.stream);
             if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
             ++device_allreduce_calls;
             device_allreduce_doubles += count;
-            st.pack_dev.download(st.pin_packed.p + off, static_cast<size_t>(count), e.stream, static_cast<size_t>(off));
+        } else if (host_transport()) {  // gloo / MPI callback on the page-locked pack
+            wait_step();
+            ar(st.pin_packed.p + off, count);
+            if (to_device) st.pack_dev.upload(st.pin_packed.p + off, static_cast<size_t>(count), e.stream, static_cast<size_t>(off));
+            if (host_out) std::memcpy(host_out + off, st.pin_packed.p + off, sizeof(double) * static_cast<size_t>(count));
+            return;
+        } else {  // a single rank: the exchange is the identity (counted like one: the protocol does not depend on the rank count)
+            ++device_allreduce_calls;
+            device_allreduce_doubles += count;
         }
-        wait_step();
-        if (!e.rccl_comm) ar(st.pin_packed.p + off, count);  // host transport (gloo / MPI callback) or a single rank
-        std::memcpy(pack + off, st.pin_packed.p + off, sizeof(double) * static_cast<size_t>(count));
+        if (host_out) {
+            st.pack_dev.download(st.pin_packed.p + off, static_cast<size_t>(count), e.stream, static_cast<size_t>(off));
+            wait_step();
+            std::memcpy(host_out + off, st.pin_packed.p + off, sizeof(double) * static_cast<size_t>(count));
+        }
     }
     void sys_new(double huber, double radius, bool init_scale, bool constrained, const PackLayout& L, const AllReduce& ar, int rank,
                  double* pack) override {
@@ -874,6 +894,192 @@ struct HipBackend final : Backend {
                                e.blk_w_alt.p, e.blk_w.p);
         CBA_HIP(hipGetLastError());
         e.active = 1;  // bc / sd were built from copy 1 = the values copy 0 now holds
+    }
+
+    // ---- the controller form of the iteration (lm_core.hpp Backend::ctl_*, lm_ctl.hip) ---------------------------------------------
+    // Nothing below waits except ctl_wait(): the launch sequences are queued on the engine's stream, the controller kernel behind
+    // the exchange decides, and what the host needs to know arrives in the control record.
+    bool ctl_constrained = false;
+    int64_t ctl_invocations = 0;
+    void ensure_ctl(const PackLayout& L) {
+        const Structure& s = st.s;
+        const int n = s.nsh;
+        const int lda = n | 1;
+        const bool lds = lm_ctl_fits_lds(n);
+        const size_t o_scal = 0, o_lmp = CS_COUNT, o_Hcc = o_lmp + 8, o_gc = o_Hcc + static_cast<size_t>(n) * n, o_scale2 = o_gc + n,
+                     o_xs = o_scale2 + n, o_rdiag = o_xs + n, o_xtmp = o_rdiag + n, o_A = o_xtmp + e.pk_size,
+                     total = o_A + (lds ? 8 : static_cast<size_t>(n + 1) * lda);
+        if (st.ctl_n != n || st.ctl_buf.n < total) {
+            st.ctl_buf.alloc(total);
+            st.ctl_buf.zero(e.stream);
+            st.ctl_idx.alloc(static_cast<size_t>(std::max(1, n)));
+            st.ctl_eff.alloc(static_cast<size_t>(std::max(1, n)));
+            st.ctl_rec.reserve(CTL_REC_FETCH + e.pk_size + static_cast<size_t>(n) + 8);
+            st.ctl_n = n;
+        }
+        CtlView& V = st.ctl_view;
+        V.n = n; V.n_cams = s.n_cams; V.PI = s.PI; V.PL = s.PL; V.NH = s.NH; V.NACC = s.NACC; V.PC = s.PC; V.sh_base = s.sh_base;
+        V.chain = s.chain; V.n_ranks = L.n_ranks;
+        V.off_stats = L.stats; V.off_cam = L.cam; V.off_cost = L.cost; V.off_nfail = L.nfail; V.off_S = L.S; V.off_g = L.g; V.off_gmax = L.gmax;
+        V.pk_cam = static_cast<int64_t>(e.pk_cam); V.pk_target = static_cast<int64_t>(e.pk_target); V.pk_delta = static_cast<int64_t>(e.pk_delta);
+        double* b = st.ctl_buf.p;
+        V.x_cur = e.shared_pack[0].p; V.x_trial = e.shared_pack[1].p; V.x_tmp = b + o_xtmp;
+        V.scal = b + o_scal; V.lmp = b + o_lmp; V.Hcc = b + o_Hcc; V.gc = b + o_gc; V.scale2 = b + o_scale2; V.xs = b + o_xs;
+        V.rdiag = b + o_rdiag; V.A = b + o_A; V.lda = lda; V.Dk = nullptr;  // (the kernel stages the diagonal block in LDS)
+        V.pack = st.pack_dev.p;
+        V.eff = st.ctl_eff.p; V.idx = st.ctl_idx.p; V.active = st.res_active.p; V.cam_var = st.res_cam_var.p;
+        V.rec = st.ctl_rec.p;
+    }
+    void run_ctl(int mode, int flag) {
+        launch_lm_ctl(st.ctl_view, mode, flag, e.stream);
+        ++ctl_invocations;
+    }
+    bool ctl_begin(const CtlSetup& cs, const PackLayout& L) override {
+        if (!st.lm_ctl_mode) return false;
+        const Structure& s = st.s;
+        ensure_pack(L);
+        ensure_ctl(L);
+        if (e.blk_acc_alt.n < e.blk_acc.n) { e.blk_acc_alt.alloc(e.blk_acc.n); e.blk_w_alt.alloc(e.blk_w.n); }
+        CtlView& V = st.ctl_view;
+        V.eps = cs.eps; V.max_iterations = cs.max_iterations; V.constrained = cs.constrained; V.line_search = cs.line_search;
+        V.speculate = (cs.speculate && !e.scalar) ? 1 : 0;  // the fp32 study mode keeps the plain sequence
+        V.intr_var = cs.intr_var; V.target_var = cs.target_var;
+        ctl_constrained = cs.constrained;
+        // masks, control scalars, [radius, init_scale] and the start point: page-locked staging, queued copies
+        st.pin_mask.reserve(static_cast<size_t>(s.nsh + s.n_cams));
+        for (int i = 0; i < s.nsh; ++i) st.pin_mask.p[i] = (*cs.active)[i];
+        for (int c = 0; c < s.n_cams; ++c) st.pin_mask.p[s.nsh + c] = (*cs.cam_var)[c];
+        st.res_active.upload(st.pin_mask.p, s.nsh, e.stream);
+        st.res_cam_var.upload(st.pin_mask.p + s.nsh, s.n_cams, e.stream);
+        double* stage = st.ctl_rec.p + CS_COUNT;  // [scal | lmp] then the start point
+        ctl_reset(stage);
+        stage[CS_COUNT] = 1e4; stage[CS_COUNT + 1] = 1.0;
+        st.ctl_buf.upload(stage, CS_COUNT + 2, e.stream);
+        for (int k = 0; k < CS_COUNT; ++k) st.ctl_rec.p[k] = 0.0;
+        double* pk = st.pin_pack[0].p;
+        std::memcpy(pk, cs.intr, sizeof(double) * e.h_intr.size());
+        if (e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(pk + e.pk_cam, cs.cam, sizeof(double) * e.h_cam.size());
+        if (e.chain == CBA_CHAIN_BUNDLE) std::memcpy(pk + e.pk_target, cs.target, sizeof(double) * 7);
+        e.shared_pack[0].upload(pk, e.pk_delta, e.stream);
+        e.shared_pack[1].upload(pk, e.pk_delta, e.stream);
+        lmp_src = V.lmp;
+        ctl_invocations = 0;
+        st.current_is_on_device = false;
+        return true;
+    }
+    void ctl_new(double huber, bool first, const PackLayout& L, const AllReduce& ar, int rank) override {
+        (void)rank;
+        const Structure& s = st.s;
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        if (q1) enqueue_normal_eq(huber, 0, pack_target() + L.cam, st.stat_dev.p + 4);
+        if (q2) enqueue_schur(ctl_constrained, 0, st.sys_tiles.p);
+        enqueue_pack(L, q1, q2, 0);
+        exchange(L.cam, L.size - L.cam, ar, nullptr, true);
+        run_ctl(CTL_NEW, first ? 1 : 0);
+        e.active = 0;
+    }
+    void ctl_resolve(const PackLayout& L, const AllReduce& ar, int rank) override {
+        (void)rank;
+        const Structure& s = st.s;
+        const bool q2 = s.n_views != 0;
+        if (q2) enqueue_schur(ctl_constrained, 0, st.sys_tiles.p);
+        enqueue_pack(L, s.n_blocks != 0, q2, 0, 0);  // only [nfail .. g] travels
+        exchange(L.nfail, L.gmax - L.nfail, ar, nullptr, true);
+        run_ctl(CTL_RESOLVED, 0);
+    }
+    void enqueue_backsub() {  // delta_p, trial poses (copy 1) and the views' share of the step statistics, from the CURRENT factors
+        const Structure& s = st.s;
+        hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)),
+                           st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p, st.link_blk.p, e.d_blk_cam.p,
+                           e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.view[0].p,
+                           st.view_delta.p, e.view[1].p, st.view_stats.p);
+        hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p, static_cast<const double*>(nullptr),
+                           st.stat_dev.p);
+    }
+    void ctl_step(double huber, bool speculative, const PackLayout& L, const AllReduce& ar, int rank) override {
+        (void)rank;
+        const Structure& s = st.s;
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        // the shared trial blocks and the shared step are where the controller left them (copy 1)
+        if (q2) enqueue_backsub();
+        else CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        if (speculative) {
+            // linearise at the trial point into the second set of block sums / weights; the current set stays valid for a rejected step
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+            try {
+                if (q1) enqueue_normal_eq(huber, 1, pack_target() + L.cam, st.stat_dev.p + 4);
+                if (q2) enqueue_schur(ctl_constrained, 1, st.sys_tiles.p);  // with the radius the controller predicted
+            } catch (...) {
+                std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+                std::swap(e.blk_w.p, e.blk_w_alt.p);
+                throw;
+            }
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+            enqueue_pack(L, q1, q2, 1);
+            exchange(0, L.size, ar, nullptr, true);
+        } else {
+            if (q1) {  // the cost alone (Mode R); the block sums / weights of the current point stay
+                launch_block_consts(e, 1);
+                launch_resid(e);
+                launch_cost(e, huber, st.stat_dev.p + 4);
+            } else {
+                CBA_HIP(hipMemsetAsync(st.stat_dev.p + 4, 0, sizeof(double), e.stream));
+            }
+            enqueue_pack(L, false, false, 1, 1);
+            exchange(L.stats, 6, ar, nullptr, true);
+        }
+        run_ctl(CTL_STEP, speculative ? 1 : 0);
+        e.active = 1;
+    }
+    // trial -> current without a copy: the two sets of private poses (and, after a speculative step, of block sums and weights)
+    // trade places.  A stage graph captured with the old pointers would be stale: the captured stages belong to the host-side
+    // form of the iteration, which is not running; they are dropped and re-captured if it ever runs again.
+    void ctl_accept(bool blocks) override {
+        std::swap(e.view[0].p, e.view[1].p);
+        if (blocks) {
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+        }
+        for (HipLMState::GraphSlot* g : {&st.g_new, &st.g_schur, &st.g_trial})
+            if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; g->uses = 0; }
+    }
+    const double* ctl_wait() override {
+        // the controller publishes the record's sequence number last (system-scope release): poll it, fall back to the stream
+        volatile const double* seq = st.ctl_rec.p + CS_SEQ;
+        const double want = static_cast<double>(ctl_invocations);
+        if (st.sync_spin) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 0; *seq < want; ++spins) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(st.ctl_poll_us)) break;
+            }
+        }
+        if (*seq < want) {
+            CBA_HIP(hipStreamSynchronize(e.stream));
+            if (*seq < want) throw HipError("LM controller: the control record did not arrive");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return st.ctl_rec.p;
+    }
+    void ctl_fetch(double* intr, double* cam, double* target, double* delta) override {
+        double* stage = st.ctl_rec.p + CTL_REC_FETCH;
+        e.shared_pack[0].download(stage, e.pk_delta, e.stream);
+        e.shared_pack[1].download(stage + e.pk_delta, static_cast<size_t>(st.s.nsh), e.stream, e.pk_delta);
+        CBA_HIP(hipStreamSynchronize(e.stream));
+        std::memcpy(intr, stage, sizeof(double) * e.h_intr.size());
+        if (e.chain != CBA_CHAIN_INTRINSIC) std::memcpy(cam, stage + e.pk_cam, sizeof(double) * e.h_cam.size());
+        if (e.chain == CBA_CHAIN_BUNDLE) std::memcpy(target, stage + e.pk_target, sizeof(double) * 7);
+        std::memcpy(delta, stage + e.pk_delta, sizeof(double) * static_cast<size_t>(st.s.nsh));
+    }
+    void ctl_line_search_done(const double* scal) override {
+        double* stage = st.ctl_rec.p + CS_COUNT;
+        std::memcpy(stage, scal, sizeof(double) * CS_COUNT);
+        st.ctl_buf.upload(stage, CS_COUNT, e.stream);
+        run_ctl(CTL_LS_DONE, 0);
     }
 
     void trial(const double* delta_sh, double huber, TrialStats* out) override {
@@ -1003,6 +1209,9 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->res_Hcc.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_Ssch.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_out.alloc(32);
+    if (const char* env = std::getenv("CBA_LM_CTL")) st->lm_ctl_mode = std::atoi(env) != 0;
+    if (const char* env = std::getenv("CBA_LM_CTL_POLL_US")) st->ctl_poll_us = std::atoi(env);
+    warm_lm_ctl();
     if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_RESIDENT_MAX_OBS")) st->resident_max_obs = std::atoll(env);
     CBA_HIP(hipStreamSynchronize(e.stream));
@@ -1014,8 +1223,10 @@ void solve_stats(const Engine& e, int64_t stats8[8]) {
 }
 
 void set_lm_mode(Engine& e, int mode) {
-    if (mode < 0 || mode > 2) throw std::invalid_argument("lm mode: 0 host-driven, 1 automatic, 2 resident whenever possible");
-    lm_state(e)->resident_mode = mode;
+    if (mode < 0 || mode > 3)
+        throw std::invalid_argument("lm mode: 0 chip-wide kernels, 1 automatic, 2 resident kernel whenever possible, 3 chip-wide kernels with the host-side iteration (diagnosis)");
+    lm_state(e)->resident_mode = mode == 3 ? 0 : mode;
+    lm_state(e)->lm_ctl_mode = mode == 3 ? 0 : 1;
 }
 
 void engine_allreduce(Engine& e, double* buf, int64_t n) {
@@ -1115,6 +1326,13 @@ void warm_lm(Engine& e) {
         // accept_step is set up by an empty launch)
         hipLaunchKernelGGL(k_accept_blocks, dim3(1), dim3(64), 0, e.stream, static_cast<int64_t>(0), e.blk_acc_alt.p, e.blk_acc.p,
                            static_cast<int64_t>(0), e.blk_w_alt.p, e.blk_w.p);
+        // the controller kernel: one invocation out of turn (the control scalars say the solve has ended: it changes nothing)
+        be.ensure_ctl(L);
+        double* stage = lm_state(e)->ctl_rec.p + CS_COUNT;
+        ctl_reset(stage);
+        stage[CS_TERM] = 0.0;
+        lm_state(e)->ctl_buf.upload(stage, CS_COUNT, e.stream);
+        be.run_ctl(CTL_NEW, 0);
         e.rccl_comm = comm;
     }
     lm_state(e)->g_new.uses = lm_state(e)->g_schur.uses = lm_state(e)->g_trial.uses = 0;

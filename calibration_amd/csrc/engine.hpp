@@ -90,8 +90,8 @@ struct DevBuf {
         p = static_cast<T*>(cache_alloc(false, count * sizeof(T), &granted));
         n = count;
     }
-    void upload(const T* src, size_t count, hipStream_t s) {
-        if (count) CBA_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    void upload(const T* src, size_t count, hipStream_t s, size_t first = 0) {
+        if (count) CBA_HIP(hipMemcpyAsync(p + first, src, count * sizeof(T), hipMemcpyHostToDevice, s));
     }
     void download(T* dst, size_t count, hipStream_t s, size_t first = 0) const {
         if (count) CBA_HIP(hipMemcpyAsync(dst, p + first, count * sizeof(T), hipMemcpyDeviceToHost, s));

@@ -31,6 +31,7 @@
 
 #include "dense.hpp"
 #include "line_search.hpp"
+#include "lm_ctl.hpp"
 #include "reproj_math.hpp"
 #include "schur_math.hpp"
 #include "structure.hpp"
@@ -47,7 +48,8 @@ using AllReduce = std::function<void(double*, int64_t)>;
 
 // Layout of the ONE packed buffer a linear solve exchanges between ranks: everything is a sum over ranks;
 // the private-gradient max travels as one slot per rank (sum of a one-hot vector), so a single sum-all-reduce serves all.
-//   [ step statistics (6) | per-camera weighted sums (n_cams * NACC) | cost | #failed views | S_schur (n*n) | g_schur (n) | gmax slots ]
+//   [ step statistics (6) | per-camera weighted sums (n_cams * NACC) | cost | #failed views | S_schur (upper triangle, packed
+//     row-major: n (n + 1) / 2) | g_schur (n) | gmax slots ]
 struct PackLayout {
     int64_t stats = 0, cam = 6, cost = 0, nfail = 0, S = 0, g = 0, gmax = 0, size = 0;
     int n = 0, n_ranks = 1;
@@ -58,9 +60,23 @@ struct PackLayout {
         cost = cam + static_cast<int64_t>(s.n_cams) * s.NACC;
         nfail = cost + 1;
         S = nfail + 1;
-        g = S + static_cast<int64_t>(n) * n;
+        g = S + static_cast<int64_t>(n) * (n + 1) / 2;
         gmax = g + n;
         size = gmax + n_ranks;
+    }
+    // the symmetric n x n matrix <-> its packed upper triangle in the pack
+    void pack_S(const std::vector<double>& full, double* dst) const {
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) *dst++ = full[static_cast<size_t>(i) * n + j];
+    }
+    void unpack_S(const double* src, std::vector<double>& full) const {
+        full.resize(static_cast<size_t>(n) * n);
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) {
+                const double v = *src++;
+                full[static_cast<size_t>(i) * n + j] = v;
+                full[static_cast<size_t>(j) * n + i] = v;
+            }
     }
 };
 
@@ -101,7 +117,7 @@ struct Backend {
         std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
         pack[L.cost] = cost2[0];
         pack[L.nfail] = nf;
-        std::copy(S.begin(), S.end(), pack + L.S);
+        L.pack_S(S, pack + L.S);
         std::copy(g.begin(), g.end(), pack + L.g);
         pack[L.gmax + rank] = gm;
         ar(pack + L.cam, L.size - L.cam);
@@ -113,7 +129,7 @@ struct Backend {
         int nf = 0;
         schur(radius, false, constrained, S, g, &gm, &nf);
         pack[L.nfail] = nf;
-        std::copy(S.begin(), S.end(), pack + L.S);
+        L.pack_S(S, pack + L.S);
         std::copy(g.begin(), g.end(), pack + L.g);
         ar(pack + L.nfail, L.gmax - L.nfail);
         (void)rank;
@@ -138,6 +154,33 @@ struct Backend {
     virtual void line_eval(double a, double huber, bool want_slope, const PackLayout& L, const AllReduce& ar, int rank, double* pack) = 0;
     // collectives the backend issued itself (device-side packing + RCCL): the driver adds them to its ExchangeStats
     int64_t device_allreduce_calls = 0, device_allreduce_doubles = 0;
+
+    // ---- the controller form of the iteration (lm_ctl.hpp): the reduced solve, the step decision and the shared parameter
+    // blocks live with the backend (in device memory on the GPU); the driver only reads the control record the controller
+    // publishes after every exchange and queues the launch sequence it asks for.  Every ctl_* call below queues work and returns;
+    // ctl_wait() returns the record of the LAST queued controller invocation.
+    struct CtlSetup {
+        double eps = 0;
+        int max_iterations = 0;
+        bool constrained = false, line_search = true, speculate = true, intr_var = true, target_var = false;
+        const std::vector<char>*active = nullptr, *cam_var = nullptr;
+        const double *intr = nullptr, *cam = nullptr, *target = nullptr;  // the start point (projected onto the bounds)
+    };
+    virtual bool ctl_begin(const CtlSetup& cs, const PackLayout& L) { (void)cs; (void)L; return false; }  // false: no controller
+    // linearise at the current point, eliminate with the controller's radius, pack, ONE exchange, controller (CTL_NEW)
+    virtual void ctl_new(double huber, bool first, const PackLayout& L, const AllReduce& ar, int rank) { (void)huber; (void)first; (void)L; (void)ar; (void)rank; }
+    // eliminate the current linearisation again with the controller's radius, pack, ONE exchange, controller (CTL_RESOLVED)
+    virtual void ctl_resolve(const PackLayout& L, const AllReduce& ar, int rank) { (void)L; (void)ar; (void)rank; }
+    // the pending trial step (its shared part is the controller's): back-substitution, then the cost at the trial point or
+    // (speculative) its linearisation and elimination with the predicted radius; pack, ONE exchange, controller (CTL_STEP)
+    virtual void ctl_step(double huber, bool speculative, const PackLayout& L, const AllReduce& ar, int rank) { (void)huber; (void)speculative; (void)L; (void)ar; (void)rank; }
+    // the last trial was accepted: private poses (and, after a speculative step, block sums and weights) trial -> current
+    virtual void ctl_accept(bool blocks) { (void)blocks; }
+    virtual const double* ctl_wait() { return nullptr; }
+    // current shared blocks and the pending shared step, for the host side of a line search / the end of the solve
+    virtual void ctl_fetch(double* intr, double* cam, double* target, double* delta) { (void)intr; (void)cam; (void)target; (void)delta; }
+    // the host ran a line search on the pending step: scal = the control scalars with CS_LS_* filled in; controller (CTL_LS_DONE)
+    virtual void ctl_line_search_done(const double* scal) { (void)scal; }
 };
 
 // what a solve exchanged (cba_reproj_solve_stats)
@@ -164,11 +207,14 @@ class LMDriver {
         pack_.assign(static_cast<size_t>(L_.size), 0.0);
         if (const char* env = std::getenv("CBA_LM_SPECULATE")) speculate_ = std::atoi(env) != 0;
         if (const char* env = std::getenv("CBA_LM_LINE_SEARCH")) line_search_ = std::atoi(env) != 0;
+        if (const char* env = std::getenv("CBA_LM_CTL")) use_ctl_ = std::atoi(env) != 0;
+        if (const char* env = std::getenv("CBA_LM_PIPELINE")) pipeline_ = std::atoi(env) != 0;
     }
     LMDriver(const LMDriver&) = delete;  // ar_ captures `this`
     LMDriver& operator=(const LMDriver&) = delete;
     void set_speculate(bool on) { speculate_ = on; }
     void set_line_search(bool on) { line_search_ = on; }
+    void set_controller(bool on) { use_ctl_ = on; }  // false: the host-side form of the iteration (comparison / diagnosis)
     const ExchangeStats& exchange_stats() const { return xs_; }
 
     // ---- masks: which blocks Ceres would hold constant ----------------------------------------
@@ -219,6 +265,153 @@ class LMDriver {
     }
 
     void solve(const cba_options& o, cba_summary* out) {
+        if (use_ctl_ && solve_ctl(o, out)) return;
+        solve_host(o, out);
+    }
+
+    // The iteration with the controller (lm_ctl.hpp) next to the data: this loop takes no decision and does no arithmetic on
+    // the reduced system — it reads the control record and queues what the record asks for.  One wait per trial step; a
+    // re-elimination (rejected step, radius miss) and the trial step behind it are queued together.
+    bool solve_ctl(const cba_options& o, cba_summary* out) {
+        const auto t0 = std::chrono::steady_clock::now();
+        setup(o);
+        const double huber = o.huber_delta;
+        project_shared();
+        xs_ = ExchangeStats();
+        Backend::CtlSetup cs;
+        cs.eps = o.epsilon; cs.max_iterations = o.max_iterations;
+        cs.constrained = constrained_; cs.line_search = line_search_; cs.speculate = speculate_;
+        cs.intr_var = intr_var_; cs.target_var = target_var_;
+        cs.active = &active_; cs.cam_var = &cam_var_;
+        cs.intr = intr_.data(); cs.cam = cam_.data(); cs.target = target_.data();
+        if (!be_.ctl_begin(cs, L_)) return false;
+        static const bool timing = [] { const char* e = std::getenv("CBA_LM_TIMING"); return e && e[0] == '1'; }();
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        double t_wait = 0, t_queue = 0;
+        int n_waits = 0;
+        double rec[CS_COUNT];
+        auto wait = [&] {
+            const auto a = now();
+            const double* r = be_.ctl_wait();
+            std::memcpy(rec, r, sizeof(rec));
+            t_wait += us(a, now());
+            ++n_waits;
+        };
+        be_.ctl_new(huber, true, L_, ar_, rank_);
+        wait();
+        double last_printed = 0;
+        while (rec[CS_TERM] < 0.0) {
+            const auto q0 = now();
+            const int expect = static_cast<int>(rec[CS_EXPECT]);
+            if (o.verbose && rec[CS_P_ITER] > last_printed) {
+                last_printed = rec[CS_P_ITER];
+                std::printf("[cba] it %3d cost %.12e cand %.12e rel %.3e radius %.3e |g| %.3e%s\n", static_cast<int>(rec[CS_P_ITER]),
+                            rec[CS_P_COST], rec[CS_CAND_COST], rec[CS_REL], rec[CS_P_RADIUS], rec[CS_P_GMAX],
+                            rec[CS_SPECULATED] != 0.0 ? " (speculative)" : "");
+            }
+            if (rec[CS_ACCEPT] != 0.0) be_.ctl_accept(rec[CS_ACCEPT] == 2.0);
+            if (expect == CTL_STEP) {
+                be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
+            } else if (expect == CTL_RESOLVED) {
+                be_.ctl_resolve(L_, ar_, rank_);
+                // what follows the re-elimination does not depend on its result (unless the reduced system turns out unsolvable,
+                // in which case the controller ignores the step): queue it behind, one wait for both
+                if (pipeline_ && rec[CS_WILL_END] == 0.0) be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
+            } else if (expect == CTL_NEW) {
+                be_.ctl_new(huber, false, L_, ar_, rank_);
+            } else if (expect == CTL_LINE_SEARCH) {
+                ctl_line_search(huber, rec);
+            } else {
+                throw std::runtime_error("LM controller: unexpected request");
+            }
+            t_queue += us(q0, now());
+            wait();
+        }
+        // the accepted point: shared blocks from the controller, private poses from the backend
+        {
+            std::vector<double> d(std::max(1, s_.nsh));
+            be_.ctl_fetch(intr_.data(), cam_.data(), target_.data(), d.data());
+        }
+        if (!view_.empty()) be_.download_private(view_.data());
+        xs_.allreduce_calls += be_.device_allreduce_calls;
+        xs_.allreduce_doubles += be_.device_allreduce_doubles;
+        be_.device_allreduce_calls = be_.device_allreduce_doubles = 0;
+        xs_.speculative_steps = static_cast<int32_t>(rec[CS_N_SPEC]);
+        xs_.speculation_hits = static_cast<int32_t>(rec[CS_N_HITS]);
+        xs_.speculation_misses = static_cast<int32_t>(rec[CS_N_MISSES]);
+        xs_.rejected_steps = static_cast<int32_t>(rec[CS_N_REJECTED]);
+        cost_ = rec[CS_COST];
+        const int term = static_cast<int>(rec[CS_TERM]), iter = static_cast<int>(rec[CS_ITER]);
+        out->termination = term;
+        out->success = term == CBA_TERM_CONVERGENCE;
+        out->iterations = iter;
+        out->successful_steps = static_cast<int>(rec[CS_SUCCESSFUL]);
+        out->initial_cost = rec[CS_INITIAL_COST];
+        out->final_cost = cost_;
+        out->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timing)
+            std::fprintf(stderr, "[cba timing] solve %.1f us, %d iterations, %d waits: waiting %.1f us, host between a wait and the end of its "
+                         "launches %.1f us (%.1f per wait), controller invocations out of turn %d\n", out->solve_seconds * 1e6, iter, n_waits,
+                         t_wait, t_queue, t_queue / std::max(1, n_waits), static_cast<int>(rec[CS_N_WASTED]));
+        std::snprintf(out->report, sizeof(out->report), "calibba(schur LM, %d rank%s): %s iters=%d cost %.6e -> %.6e", n_ranks_,
+                      n_ranks_ > 1 ? "s" : "", ctl_message(static_cast<int>(rec[CS_MSG])), iter, out->initial_cost, cost_);
+        return true;
+    }
+
+    // Ceres' projected line search on the pending step of a bounds-constrained problem, which failed the Armijo test at step
+    // size 1 (line_search.hpp): the samples are queued from here (a handful per search, rare); the decision on the step found goes
+    // back to the controller.
+    void ctl_line_search(double huber, const double* rec) {
+        const int n = s_.nsh;
+        ++xs_.line_searches;
+        std::vector<double> full(n), scaled(n), tintr, tcam, ttarget;
+        be_.ctl_fetch(intr_.data(), cam_.data(), target_.data(), full.data());
+        const double cost0 = rec[CS_COST], slope0 = rec[CS_SLOPE0], dmax = rec[CS_DMAX];
+        double step2_sh = 0, xnorm2_sh = 0;
+        auto sample = [&](double a, bool with_slope) {
+            for (int i = 0; i < n; ++i) scaled[i] = a * full[i];
+            shared_plus(scaled, tintr, tcam, ttarget, &step2_sh, &xnorm2_sh);
+            be_.upload_shared(1, tintr.data(), tcam.data(), ttarget.data());
+            be_.line_eval(a, huber, with_slope, L_, ar_, rank_, pack_.data());
+            LineSample ls;
+            ls.step = a;
+            ls.value = pack_[L_.stats + PackLayout::TRIAL_COST];
+            ls.has_value = std::isfinite(ls.value);
+            if (with_slope && ls.has_value) {
+                const std::vector<double> cam_acc(pack_.begin() + L_.cam, pack_.begin() + L_.cost);
+                std::vector<double> Ht(static_cast<size_t>(n) * n), gt(n);
+                assemble_shared(cam_acc, Ht, gt);
+                double sl = pack_[L_.stats + PackLayout::SLOPE];
+                for (int i = 0; i < n; ++i) sl += gt[i] * full[i];  // (full is zero on inactive columns)
+                ls.slope = sl;
+                ls.has_slope = std::isfinite(sl);
+            }
+            return ls;
+        };
+        int evals = 0;
+        double a = armijo_line_search(cost0, slope0, dmax, sample, &evals);
+        xs_.line_search_evaluations += evals;
+        if (!(a > 0.0)) {  // search failed: the full step, re-established on the device (one more sample)
+            a = 1.0;
+            (void)sample(1.0, false);
+            ++xs_.line_search_evaluations;
+        }
+        double scal[CS_COUNT];
+        std::memcpy(scal, rec, sizeof(scal));
+        scal[CS_LS_A] = a;
+        scal[CS_LS_COST] = pack_[L_.stats + PackLayout::TRIAL_COST];
+        scal[CS_LS_STEP2] = pack_[L_.stats + PackLayout::STEP2];
+        scal[CS_LS_XNORM2] = pack_[L_.stats + PackLayout::XNORM2];
+        scal[CS_LS_STEP2_SH] = step2_sh;
+        scal[CS_LS_XNORM2_SH] = xnorm2_sh;
+        scal[CS_EXPECT] = CTL_LS_DONE;
+        be_.ctl_line_search_done(scal);
+    }
+
+    void solve_host(const cba_options& o, cba_summary* out) {
         const auto t0 = std::chrono::steady_clock::now();
         setup(o);
         const int n = s_.nsh;
@@ -655,7 +848,7 @@ class LMDriver {
         const std::vector<double> cam_acc(pack_.begin() + L_.cam, pack_.begin() + L_.cost);
         cost_ = pack_[L_.cost];
         nfail_ = static_cast<int>(pack_[L_.nfail] + 0.5);
-        Ssch_.assign(pack_.begin() + L_.S, pack_.begin() + L_.g);
+        L_.unpack_S(pack_.data() + L_.S, Ssch_);
         gsch_.assign(pack_.begin() + L_.g, pack_.begin() + L_.gmax);
         double gm = 0;
         for (int r = 0; r < n_ranks_; ++r) gm = std::max(gm, pack_[L_.gmax + r]);  // max over ranks via per-rank slots
@@ -678,7 +871,7 @@ class LMDriver {
     void resolve(double radius) {
         be_.sys_resolve(radius, constrained_, L_, ar_, rank_, pack_.data());
         nfail_ = static_cast<int>(pack_[L_.nfail] + 0.5);
-        Ssch_.assign(pack_.begin() + L_.S, pack_.begin() + L_.g);
+        L_.unpack_S(pack_.data() + L_.S, Ssch_);
         gsch_.assign(pack_.begin() + L_.g, pack_.begin() + L_.gmax);
     }
 
@@ -782,6 +975,8 @@ class LMDriver {
     std::vector<double> pack_;
     bool speculate_ = true;
     bool line_search_ = true;
+    bool use_ctl_ = true;    // the controller form of the iteration when the backend has one (CBA_LM_CTL=0: host-side form)
+    bool pipeline_ = true;   // queue a re-elimination and the step behind it together (CBA_LM_PIPELINE=0: one wait each)
     ExchangeStats xs_;
     std::vector<char> active_, eff_;
     std::vector<char> cam_var_;

@@ -1,0 +1,669 @@
+// lm_ctl.hpp — the CONTROLLER of the Levenberg-Marquardt iteration as __host__ __device__ code: everything the solve does on the
+// reduced (shared) system between two exchanges — adopt an all-reduced linearisation (H_cc, g_c, effective columns, Jacobi scale,
+// gradient max-norm), factorise and solve (H_cc + D - S) d = -(g_c - g_s), Plus on the shared blocks, the model-cost terms, the
+// gain ratio, accept / reject, the radius update, the convergence tests — for ONE cooperating team of threads.
+//
+// On the GPU the team is one workgroup (lm_ctl.hip: k_lm_ctl, launched on the engine's stream right behind the packed exchange),
+// so an LM step never leaves the device: `k_pack -> ncclAllReduce -> k_lm_ctl`, and the host merely reads the control record
+// the kernel publishes to learn which launch sequence comes next.  tests/cpu_backend instantiates the same code with a team
+// of one host thread (SerialTeam), which is how the CPU tier checks the decisions and the exchange protocol without a GPU.
+//
+// Restates what the reference delegates to ceres::Solve (src/estimation/detail/ceresutils.h:27-43): Ceres 2.x
+// TrustRegionMinimizer + LevenbergMarquardtStrategy with the reference's options (tolerances = epsilon, max_num_iterations) and
+// Ceres' defaults; rules and constants as in lm_core.hpp (which keeps the host-side form of the same iteration for comparison).
+// Ceres is a third-party dependency absent from /root/reference: parity with its own iteration numerics is unpinned.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/calibba.h"
+#include "reproj_math.hpp"
+#include "schur_math.hpp"
+
+namespace cba {
+
+// ---- control scalars (doubles; CtlView::scal, published verbatim as the control record) -----------------------------------
+enum CtlSlot : int {
+    CS_SEQ = 0,        // number of controller invocations so far (the host waits for its own count)
+    CS_TERM,           // -1 while the solve runs, else CBA_TERM_*
+    CS_MSG,            // CtlMsg
+    CS_EXPECT,         // the controller mode that must run next (CtlMode; 0 = none: the solve has ended)
+    CS_STEP_SPEC,      // the next trial step is evaluated speculatively (linearised at the trial point) / the cheap way (cost only)
+    CS_ACCEPT,         // 0 nothing; 1 the last trial was accepted after a plain evaluation (private poses trial -> current);
+                       // 2 accepted after a speculative one (poses + block sums + weights)
+    CS_WILL_END,       // with CS_EXPECT = RESOLVED: the loop-top tests after the re-elimination will end the solve (no step follows)
+    CS_RADIUS, CS_DECREASE, CS_RADIUS_SPEC, CS_COST, CS_GMAX, CS_GMAX_PRIV, CS_INITIAL_COST, CS_REL_LAST, CS_REL_PREV,
+    CS_ITER, CS_SUCCESSFUL, CS_INVALID, CS_VALID, CS_PLAIN_NEXT, CS_NFAIL, CS_M,
+    CS_STEP2_SH, CS_XNORM2_SH, CS_GD_SH, CS_DHD_SH, CS_DMAX,     // the shared blocks' share of the pending step's statistics
+    CS_CAND_COST, CS_REL, CS_MODEL_CHANGE, CS_SLOPE0, CS_SPECULATED,
+    CS_P_COST, CS_P_RADIUS, CS_P_GMAX, CS_P_ITER,                // the state a decision was taken in (verbose output)
+    CS_N_SPEC, CS_N_HITS, CS_N_MISSES, CS_N_REJECTED, CS_N_WASTED,
+    CS_LS_A, CS_LS_COST, CS_LS_STEP2, CS_LS_XNORM2, CS_LS_STEP2_SH, CS_LS_XNORM2_SH,  // host -> controller: result of a line search
+    CS_COUNT = 64
+};
+static_assert(CS_LS_XNORM2_SH < CS_COUNT, "control record size");
+
+enum CtlMode : int { CTL_NONE = 0, CTL_NEW = 1, CTL_RESOLVED = 2, CTL_STEP = 3, CTL_LS_DONE = 4, CTL_LINE_SEARCH = 5 };
+enum CtlMsg : int { CM_GRADIENT = 0, CM_MAX_ITER, CM_MIN_RADIUS, CM_INVALID_STEPS, CM_PARAMETER, CM_FUNCTION, CM_NONE };
+inline const char* ctl_message(int m) {
+    static const char* const k[] = {"Gradient tolerance reached.", "Maximum number of iterations reached.",
+                                    "Minimum trust region radius reached.", "Number of consecutive invalid steps more than max.",
+                                    "Parameter tolerance reached.", "Function tolerance reached.", ""};
+    return k[m < 0 || m > CM_NONE ? CM_NONE : m];
+}
+
+constexpr int CTL_NB = 8;  // panel width of the blocked factorisation
+constexpr int CTL_LDS_MAX_N = 128;  // the GPU controller keeps the reduced matrix in LDS up to this size (129 x 129 doubles = 133 KB)
+
+// Everything the controller touches, as raw pointers (device memory on the GPU, host vectors in the CPU test build).
+struct CtlView {
+    // structure (structure.hpp)
+    int n, n_cams, PI, PL, NH, NACC, PC, sh_base, chain, n_ranks;
+    // pack layout (lm_core.hpp PackLayout)
+    int64_t off_stats, off_cam, off_cost, off_nfail, off_S, off_g, off_gmax;
+    // options
+    double eps;
+    int max_iterations, constrained, line_search, speculate, intr_var, target_var;
+    // shared parameter packs [intr | cam poses | target pose | (trial only) shared step]
+    int64_t pk_cam, pk_target, pk_delta;
+    double *x_cur, *x_trial, *x_tmp;
+    // state
+    double* scal;          // [CS_COUNT]
+    const double* pack;    // the all-reduced pack of the exchange this invocation follows
+    double *Hcc, *gc, *scale2;
+    int8_t* eff;
+    const int8_t *active, *cam_var;
+    int* idx;              // effective columns, compact
+    // work
+    double* A;             // (m + 1) x lda: reduced matrix -> its lower factor; row m carries the right-hand side
+    int lda;
+    double *rdiag, *xs, *Dk;  // reciprocal pivots [n], solution in compact order [n], staged diagonal block [NB * NB]
+    double* lmp;           // [radius of the next elimination, init_scale]: read by the per-view elimination kernels
+    double* rec;           // where the control record is published (page-locked host memory on the GPU)
+};
+
+struct SerialTeam {
+    CBA_HD int tid() const { return 0; }
+    CBA_HD int size() const { return 1; }
+    CBA_HD void sync() const {}
+    CBA_HD double sum(double v) const { return v; }
+    CBA_HD double max(double v) const { return v; }
+    CBA_HD void publish(const CtlView& V) const {
+        for (int k = 1; k < CS_COUNT; ++k) V.rec[k] = V.scal[k];
+        V.rec[CS_SEQ] = V.scal[CS_SEQ];
+    }
+};
+
+CBA_HD bool ctl_finite(double x) { return fabs(x) <= 1.7976931348623157e308; }
+
+// global shared column i -> (camera, local column); camera -1 = the bundle chain's target pose (structure.hpp shared_col, inverted)
+CBA_HD void ctl_decode(const CtlView& V, int i, int* cam, int* lc) {
+    if (V.chain == CH_BUNDLE) {
+        if (i < 6) { *cam = -1; *lc = i; return; }
+        *cam = (i - 6) / V.PC;
+        *lc = 6 + (i - 6) - *cam * V.PC;
+        return;
+    }
+    *cam = i / V.PC;
+    *lc = 6 + i - *cam * V.PC;
+}
+CBA_HD int ctl_intr_base(const CtlView& V, int c) { return V.chain == CH_INTRINSIC ? 0 : V.sh_base + c * V.PC + 6; }
+CBA_HD int ctl_campose_base(const CtlView& V, int c) { return V.sh_base + c * V.PC; }
+// packed upper triangle of the n x n Schur term as it travels in the pack
+CBA_HD int64_t ctl_sidx(int n, int i, int j) { return i <= j ? static_cast<int64_t>(i) * n - static_cast<int64_t>(i) * (i - 1) / 2 + (j - i)
+                                                              : static_cast<int64_t>(j) * n - static_cast<int64_t>(j) * (j - 1) / 2 + (i - j); }
+
+// Plus on the shared blocks with the fx, fy >= 0 projection (LMDriver::shared_plus): xo = Plus(x, delta); the team's totals of
+// |xo - x|^2 and |x|^2 over the variable blocks.  xo is complete for every thread on return.
+template <class TM>
+CBA_HD void ctl_plus(TM& tm, const CtlView& V, const double* x, const double* delta, double* xo, double* step2, double* xnorm2) {
+    double s2 = 0.0, x2 = 0.0;
+    const int PI = V.PI;
+    for (int i = tm.tid(); i < V.n_cams * PI; i += tm.size()) {
+        const int c = i / PI, k = i - c * PI;
+        const double p0 = x[i];
+        double p = p0;
+        if (V.intr_var) {
+            p += delta[ctl_intr_base(V, c) + k];
+            if (k < 2) p = fmax(p, 0.0);
+            s2 += (p - p0) * (p - p0);
+            x2 += p0 * p0;
+        }
+        xo[i] = p;
+    }
+    if (V.chain != CH_INTRINSIC)
+        for (int c = tm.tid(); c < V.n_cams; c += tm.size()) {
+            const double* q = x + V.pk_cam + 7 * c;
+            double* o = xo + V.pk_cam + 7 * c;
+            for (int k = 0; k < 7; ++k) o[k] = q[k];
+            if (V.cam_var[c]) {
+                const int pb = ctl_campose_base(V, c);
+                quat_plus(q, delta + pb, o);
+                for (int k = 0; k < 3; ++k) o[4 + k] = q[4 + k] + delta[pb + 3 + k];
+                for (int k = 0; k < 7; ++k) { s2 += (o[k] - q[k]) * (o[k] - q[k]); x2 += q[k] * q[k]; }
+            }
+        }
+    if (V.chain == CH_BUNDLE && tm.tid() == tm.size() - 1) {
+        const double* q = x + V.pk_target;
+        double* o = xo + V.pk_target;
+        for (int k = 0; k < 7; ++k) o[k] = q[k];
+        if (V.target_var) {
+            quat_plus(q, delta, o);
+            for (int k = 0; k < 3; ++k) o[4 + k] = q[4 + k] + delta[3 + k];
+            for (int k = 0; k < 7; ++k) { s2 += (o[k] - q[k]) * (o[k] - q[k]); x2 += q[k] * q[k]; }
+        }
+    }
+    *step2 = tm.sum(s2);
+    *xnorm2 = tm.sum(x2);
+}
+
+// the shared blocks' share of Ceres' gradient max-norm (LMDriver::shared_gmax); clobbers xs and x_tmp
+template <class TM>
+CBA_HD double ctl_shared_gmax(TM& tm, const CtlView& V) {
+    double m = 0.0;
+    if (!V.constrained) {
+        for (int i = tm.tid(); i < V.n; i += tm.size())
+            if (V.eff[i]) m = fmax(m, fabs(V.gc[i]));
+        return tm.max(m);
+    }
+    for (int i = tm.tid(); i < V.n; i += tm.size()) V.xs[i] = V.eff[i] ? -V.gc[i] : 0.0;
+    tm.sync();
+    double s2, x2;
+    ctl_plus(tm, V, V.x_cur, V.xs, V.x_tmp, &s2, &x2);
+    for (int i = tm.tid(); i < V.n_cams * V.PI; i += tm.size()) m = fmax(m, fabs(V.x_tmp[i] - V.x_cur[i]));
+    if (V.chain != CH_INTRINSIC)
+        for (int i = tm.tid(); i < 7 * V.n_cams; i += tm.size()) m = fmax(m, fabs(V.x_tmp[V.pk_cam + i] - V.x_cur[V.pk_cam + i]));
+    if (V.chain == CH_BUNDLE)
+        for (int i = tm.tid(); i < 7; i += tm.size()) m = fmax(m, fabs(V.x_tmp[V.pk_target + i] - V.x_cur[V.pk_target + i]));
+    return tm.max(m);
+}
+
+// The pack holds an all-reduced linearisation (a new system, or an accepted speculative step): make it the current one
+// (LMDriver::adopt_system): H_cc, g_c from the per-camera sums, effective columns, Jacobi scale (first system), cost, gradient norm.
+template <class TM>
+CBA_HD void ctl_adopt(TM& tm, const CtlView& V, bool init_scale) {
+    const int n = V.n, PL = V.PL, NACC = V.NACC, NH = V.NH;
+    const double* cam_acc = V.pack + V.off_cam;
+    for (int e = tm.tid(); e < n * n + n; e += tm.size()) {
+        if (e < n * n) {
+            const int i = e / n, j = e - i * n;
+            int ci, li, cj, lj;
+            ctl_decode(V, i, &ci, &li);
+            ctl_decode(V, j, &cj, &lj);
+            double h = 0.0;
+            if (ci < 0 && cj < 0) {
+                for (int c = 0; c < V.n_cams; ++c) h += cam_acc[static_cast<int64_t>(c) * NACC + hidx_sym(PL, li, lj)];
+            } else if (ci < 0 || cj < 0 || ci == cj) {
+                h = cam_acc[static_cast<int64_t>(ci < 0 ? cj : ci) * NACC + hidx_sym(PL, li, lj)];
+            }
+            V.Hcc[e] = h;
+        } else {
+            const int i = e - n * n;
+            int ci, li;
+            ctl_decode(V, i, &ci, &li);
+            double g = 0.0;
+            if (ci < 0) {
+                for (int c = 0; c < V.n_cams; ++c) g += cam_acc[static_cast<int64_t>(c) * NACC + NH + li];
+            } else {
+                g = cam_acc[static_cast<int64_t>(ci) * NACC + NH + li];
+            }
+            V.gc[i] = g;
+        }
+    }
+    tm.sync();
+    for (int i = tm.tid(); i < n; i += tm.size()) {
+        const double hii = V.Hcc[static_cast<int64_t>(i) * n + i];
+        V.eff[i] = V.active[i] && hii != 0.0;  // columns nobody observes behave like constant blocks
+        if (init_scale) {
+            const double sc = 1.0 / (1.0 + sqrt(hii));
+            V.scale2[i] = sc * sc;
+        }
+    }
+    tm.sync();
+    if (tm.tid() == 0) {
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (V.eff[i]) V.idx[m++] = i;
+        V.scal[CS_M] = m;
+        V.scal[CS_COST] = V.pack[V.off_cost];
+        V.scal[CS_NFAIL] = floor(V.pack[V.off_nfail] + 0.5);
+        double gm = 0.0;
+        for (int r = 0; r < V.n_ranks; ++r) gm = fmax(gm, V.pack[V.off_gmax + r]);  // max over ranks through one-hot slots
+        V.scal[CS_GMAX_PRIV] = gm;
+    }
+    tm.sync();
+    const double gsh = ctl_shared_gmax(tm, V);
+    if (tm.tid() == 0) V.scal[CS_GMAX] = fmax(V.scal[CS_GMAX_PRIV], gsh);
+    tm.sync();
+}
+
+// ---- the reduced solve ---------------------------------------------------------------------------------------------------
+// In-place blocked right-looking Cholesky of the leading m x m block of A (lower, row-major, stride lda) with panels of CTL_NB
+// columns; row m of A is carried along as one more panel row, so that it leaves as L^-1 b (the forward substitution costs no
+// extra pass).  Per panel: every thread factorises the staged CTL_NB x CTL_NB diagonal block in registers (redundantly: it is a
+// latency chain, not work, and it makes the pivot test team-uniform without a broadcast), the threads owning a row write that
+// row of L / forward-substitute their panel entries, barrier, then the whole team updates the trailing matrix in 4 x 4 tiles,
+// barrier.  Dk receives the next diagonal block while it is updated.  rdiag[k] = 1 / L[k][k].  Returns false (uniformly) if a
+// pivot is not positive and finite.
+template <class TM>
+CBA_HD bool ctl_cholesky(TM& tm, double* A, int lda, int m, double* Dk, double* rdiag) {
+    constexpr int NB = CTL_NB;
+    for (int k0 = 0; k0 < m; k0 += NB) {
+        const int nb = m - k0 < NB ? m - k0 : NB;
+        // --- diagonal block (staged in Dk, lower; identity beyond nb) ---
+        double L[NB][NB], inv[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) L[i][j] = (i < nb && j < nb) ? Dk[i * NB + j] : (i == j ? 1.0 : 0.0);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double d = L[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+            if (!(d > 0.0) || !ctl_finite(d)) ok = false;
+            const double r = 1.0 / sqrt(d);
+            inv[j] = r;
+            L[j][j] = d * r;
+#pragma unroll
+            for (int i = j + 1; i < NB; ++i) {
+                double s = L[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+                L[i][j] = s * r;
+            }
+        }
+        if (!ok) return false;  // every thread saw the same numbers
+        // --- panel rows: row i of [k0, m] ---
+        for (int i = k0 + tm.tid(); i <= m; i += tm.size()) {
+            double* row = A + static_cast<int64_t>(i) * lda + k0;
+            if (i < k0 + nb) {  // a row of the diagonal block (static register indices: r is matched, not used as an index)
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+                    if (i - k0 == r) {
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) row[c] = L[r][c];
+                        rdiag[i] = inv[r];
+                    }
+            } else {
+                double x[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    double s = c < nb ? row[c] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < c; ++k) s -= x[k] * L[c][k];
+                    x[c] = s * inv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c < nb) row[c] = x[c];
+            }
+        }
+        tm.sync();
+        // --- trailing update: A[i][j] -= sum_c A[i][k0 + c] A[j][k0 + c], k0 + nb <= j <= i <= m (row m: j < m), 4 x 4 tiles ---
+        const int b0 = k0 + nb;
+        if (b0 <= m) {
+            const int nrows = m + 1 - b0;  // rows b0 .. m
+            const int nt = (nrows + 3) >> 2;
+            const int ntiles = nt * (nt + 1) / 2;
+            for (int t = tm.tid(); t < ntiles; t += tm.size()) {
+                int ti = static_cast<int>((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while (ti * (ti + 1) / 2 > t) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                const int i0 = b0 + 4 * ti, j0 = b0 + 4 * tj;
+                double pi[4][NB], pj[4][NB];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        pi[a][c] = (i0 + a <= m && c < nb) ? A[static_cast<int64_t>(i0 + a) * lda + k0 + c] : 0.0;
+                        pj[a][c] = (j0 + a < m && c < nb) ? A[static_cast<int64_t>(j0 + a) * lda + k0 + c] : 0.0;
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = i0 + a, j = j0 + b;
+                        if (i <= m && j <= i && j < m) {
+                            double s = A[static_cast<int64_t>(i) * lda + j];
+#pragma unroll
+                            for (int c = 0; c < NB; ++c) s -= pi[a][c] * pj[b][c];
+                            A[static_cast<int64_t>(i) * lda + j] = s;
+                            if (i < b0 + NB && i < m) Dk[(i - b0) * NB + (j - b0)] = s;  // the next diagonal block
+                        }
+                    }
+            }
+        }
+        tm.sync();
+    }
+    return true;
+}
+
+// x = L^-T y by panels from the last one: y = row m of A (from ctl_cholesky), x -> xs[0 .. m).  Per panel every thread solves the
+// small triangular system redundantly; the threads owning an earlier row subtract the panel's contribution from it.
+template <class TM>
+CBA_HD void ctl_backsolve(TM& tm, double* A, int lda, int m, const double* rdiag, double* xs) {
+    constexpr int NB = CTL_NB;
+    double* y = A + static_cast<int64_t>(m) * lda;
+    const int last = ((m - 1) / NB) * NB;
+    for (int k0 = last; k0 >= 0; k0 -= NB) {
+        const int nb = m - k0 < NB ? m - k0 : NB;
+        double x[NB];
+#pragma unroll
+        for (int c = NB - 1; c >= 0; --c) {
+            double s = c < nb ? y[k0 + c] : 0.0;
+#pragma unroll
+            for (int k = c + 1; k < NB; ++k)
+                if (k < nb) s -= A[static_cast<int64_t>(k0 + k) * lda + k0 + c] * x[k];
+            x[c] = c < nb ? s * rdiag[k0 + c] : 0.0;
+        }
+        tm.sync();  // every thread has read y[k0 .. k0 + nb) before anyone overwrites it
+        for (int r = tm.tid(); r < k0 + nb; r += tm.size()) {
+            if (r >= k0) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (r - k0 == c) xs[r] = x[c];
+                continue;
+            }
+            double s = y[r];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) s -= A[static_cast<int64_t>(k0 + c) * lda + r] * x[c];
+            y[r] = s;
+        }
+        tm.sync();
+    }
+}
+
+// (H_cc + D - S_schur) delta = -(g_c - g_schur) on the effective columns (LMDriver::solve_reduced); delta -> x_trial[pk_delta ..),
+// zero on the other columns.  Returns false (uniformly) when the system cannot be solved.
+template <class TM>
+CBA_HD bool ctl_solve(TM& tm, const CtlView& V, double radius) {
+    const int n = V.n, m = static_cast<int>(V.scal[CS_M]);
+    double* delta = V.x_trial + V.pk_delta;
+    for (int i = tm.tid(); i < n; i += tm.size()) delta[i] = 0.0;
+    if (V.scal[CS_NFAIL] > 0.0) { tm.sync(); return false; }
+    if (m == 0) { tm.sync(); return true; }
+    const double* S = V.pack + V.off_S;
+    const double* gs = V.pack + V.off_g;
+    for (int e = tm.tid(); e < (m + 1) * m; e += tm.size()) {
+        const int r = e / m, c = e - r * m;
+        if (r < m) {
+            if (c > r) continue;
+            const int i = V.idx[r], j = V.idx[c];
+            double val = V.Hcc[static_cast<int64_t>(i) * n + j] - S[ctl_sidx(n, i, j)];
+            if (r == c) val += lm_diag(V.Hcc[static_cast<int64_t>(i) * n + i], V.scale2[i], radius);
+            V.A[static_cast<int64_t>(r) * V.lda + c] = val;
+            if (r < CTL_NB) V.Dk[r * CTL_NB + c] = val;
+        } else {
+            const int i = V.idx[c];
+            V.A[static_cast<int64_t>(m) * V.lda + c] = -(V.gc[i] - gs[i]);
+        }
+    }
+    tm.sync();
+    if (!ctl_cholesky(tm, V.A, V.lda, m, V.Dk, V.rdiag)) return false;
+    ctl_backsolve(tm, V.A, V.lda, m, V.rdiag, V.xs);
+    double bad = 0.0;
+    for (int r = tm.tid(); r < m; r += tm.size())
+        if (!ctl_finite(V.xs[r])) bad = 1.0;
+    if (tm.max(bad) > 0.0) return false;
+    for (int r = tm.tid(); r < m; r += tm.size()) delta[V.idx[r]] = V.xs[r];
+    tm.sync();
+    return true;
+}
+
+// ---- the iteration --------------------------------------------------------------------------------------------------------
+constexpr double CTL_MIN_RADIUS = 1e-32, CTL_MAX_RADIUS = 1e16, CTL_MIN_REL_DECREASE = 1e-3;
+
+template <class TM>
+CBA_HD void ctl_end(TM& tm, const CtlView& V, int term, int msg) {
+    if (tm.tid() == 0) {
+        V.scal[CS_TERM] = term;
+        V.scal[CS_MSG] = msg;
+        V.scal[CS_EXPECT] = CTL_NONE;
+    }
+}
+
+// an invalid step: the linear solve failed or the model did not decrease (halve the radius, eliminate again)
+template <class TM>
+CBA_HD void ctl_invalid_step(TM& tm, const CtlView& V) {
+    if (tm.tid() == 0) {
+        const double inv = V.scal[CS_INVALID] + 1.0;
+        V.scal[CS_INVALID] = inv;
+        if (inv >= 5.0) {
+            V.scal[CS_TERM] = CBA_TERM_FAILURE;
+            V.scal[CS_MSG] = CM_INVALID_STEPS;
+            V.scal[CS_EXPECT] = CTL_NONE;
+        } else {
+            V.scal[CS_RADIUS] *= 0.5;
+            V.scal[CS_PLAIN_NEXT] = 1.0;
+            V.scal[CS_EXPECT] = CTL_RESOLVED;
+            V.lmp[0] = V.scal[CS_RADIUS];
+            V.lmp[1] = 0.0;
+        }
+    }
+}
+
+CBA_HD bool ctl_expect_convergence(const CtlView& V) {
+    const double rl = V.scal[CS_REL_LAST], rp = V.scal[CS_REL_PREV];
+    return rp > 0.0 && rl > 0.0 && rl * fmin(1.0, rl / rp) <= 4.0 * V.eps;
+}
+CBA_HD bool ctl_next_step_speculative(const CtlView& V) {
+    return V.speculate && V.scal[CS_PLAIN_NEXT] == 0.0 && !ctl_expect_convergence(V);
+}
+// the loop-top tests of the iteration, on the current state; 0 = go on
+CBA_HD int ctl_top_tests(const CtlView& V, int* msg) {
+    if (V.scal[CS_ITER] >= V.max_iterations) { *msg = CM_MAX_ITER; return CBA_TERM_NO_CONVERGENCE; }
+    if (V.scal[CS_GMAX] <= V.eps) { *msg = CM_GRADIENT; return CBA_TERM_CONVERGENCE; }
+    if (V.scal[CS_RADIUS] <= CTL_MIN_RADIUS) { *msg = CM_MIN_RADIUS; return CBA_TERM_CONVERGENCE; }
+    return 0;
+}
+
+// Top of an iteration on the current system: the termination tests, the reduced solve, the trial point of the shared blocks and
+// their share of the step's statistics.  Leaves CS_EXPECT = CTL_STEP (with the kind of evaluation the step gets), or a
+// re-elimination after an unsolvable system, or the end of the solve.
+template <class TM>
+CBA_HD void ctl_iterate(TM& tm, const CtlView& V) {
+    int msg = CM_NONE;
+    const int t = ctl_top_tests(V, &msg);  // uniform: scalars are read after a barrier
+    if (t) { ctl_end(tm, V, t, msg); return; }
+    tm.sync();
+    if (tm.tid() == 0) V.scal[CS_ITER] += 1.0;
+    const double radius = V.scal[CS_RADIUS];
+    const bool valid = ctl_solve(tm, V, radius);
+    if (!valid) {
+        tm.sync();
+        ctl_invalid_step(tm, V);
+        return;
+    }
+    const int n = V.n;
+    const double* delta = V.x_trial + V.pk_delta;
+    double s2, x2;
+    ctl_plus(tm, V, V.x_cur, delta, V.x_trial, &s2, &x2);
+    // the shared-shared part of Ceres' model cost change -g^T d - 1/2 d^T H d; the views contribute theirs with the step's exchange
+    double gd = 0.0, dHd = 0.0, dmax = 0.0;
+    for (int i = tm.tid(); i < n; i += tm.size()) {
+        const double di = delta[i];
+        dmax = fmax(dmax, fabs(di));
+        if (di == 0.0) continue;
+        gd += V.gc[i] * di;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += V.Hcc[static_cast<int64_t>(i) * n + j] * delta[j];
+        dHd += di * s;
+    }
+    gd = tm.sum(gd);
+    dHd = tm.sum(dHd);
+    dmax = tm.max(dmax);
+    if (tm.tid() == 0) {
+        V.scal[CS_VALID] = 1.0;
+        V.scal[CS_STEP2_SH] = s2; V.scal[CS_XNORM2_SH] = x2; V.scal[CS_GD_SH] = gd; V.scal[CS_DHD_SH] = dHd; V.scal[CS_DMAX] = dmax;
+        // the radius a gain ratio >= 0.937 leads to, in the arithmetic of the update (radius / (1/3) differs from 3 * radius by one
+        // ulp for a quarter of all doubles: the comparison after the step is exact)
+        const double rspec = fmin(CTL_MAX_RADIUS, radius / (1.0 / 3.0));
+        V.scal[CS_RADIUS_SPEC] = rspec;
+        const bool spec = ctl_next_step_speculative(V);
+        V.scal[CS_STEP_SPEC] = spec ? 1.0 : 0.0;
+        V.scal[CS_EXPECT] = CTL_STEP;
+        V.lmp[0] = spec ? rspec : radius;  // the elimination at the trial point is made with the predicted radius
+        V.lmp[1] = 0.0;
+    }
+}
+
+// The decision on a trial step whose statistics (the views' share) arrived with the last exchange; cand / step2 / xnorm2 are the
+// totals over the whole state vector.  LMDriver::solve from "model_cost_change" to the radius update.
+template <class TM>
+CBA_HD void ctl_decide(TM& tm, const CtlView& V, bool speculated, double model_change, double cand, double step2, double xnorm2) {
+    const double eps = V.eps;
+    if (tm.tid() == 0) {
+        V.scal[CS_INVALID] = 0.0;
+        V.scal[CS_P_COST] = V.scal[CS_COST]; V.scal[CS_P_RADIUS] = V.scal[CS_RADIUS]; V.scal[CS_P_GMAX] = V.scal[CS_GMAX];
+        V.scal[CS_P_ITER] = V.scal[CS_ITER];
+    }
+    if (!ctl_finite(cand)) cand = 1.7976931348623157e308;
+    const double cost = V.scal[CS_COST];
+    const double step_norm = sqrt(step2), x_norm = sqrt(xnorm2);
+    const double cost_change = cost - cand;
+    const double rel = cost_change / model_change;
+    tm.sync();
+    if (tm.tid() == 0) { V.scal[CS_CAND_COST] = cand; V.scal[CS_REL] = rel; V.scal[CS_MODEL_CHANGE] = model_change; V.scal[CS_SPECULATED] = speculated ? 1.0 : 0.0; }
+    if (step_norm <= eps * (x_norm + eps)) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_PARAMETER); return; }
+    if (fabs(cost_change) <= eps * cost) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_FUNCTION); return; }
+    if (rel > CTL_MIN_REL_DECREASE) {
+        // accept: the shared blocks here; the host queues the copies of the private poses (and block sums) it is told about
+        for (int64_t i = tm.tid(); i < V.pk_delta; i += tm.size()) V.x_cur[i] = V.x_trial[i];
+        const double radius_old = V.scal[CS_RADIUS], rspec = V.scal[CS_RADIUS_SPEC];
+        const double t3 = 2.0 * rel - 1.0;
+        const double radius = fmin(CTL_MAX_RADIUS, radius_old / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3));
+        tm.sync();
+        if (tm.tid() == 0) {
+            V.scal[CS_SUCCESSFUL] += 1.0;
+            V.scal[CS_REL_PREV] = V.scal[CS_REL_LAST];
+            V.scal[CS_REL_LAST] = fabs(cost_change) / cost;
+            V.scal[CS_RADIUS] = radius;
+            V.scal[CS_DECREASE] = 2.0;
+            V.scal[CS_PLAIN_NEXT] = 0.0;
+            V.scal[CS_ACCEPT] = speculated ? 2.0 : 1.0;
+        }
+        tm.sync();
+        if (speculated) {
+            ctl_adopt(tm, V, false);  // the exchange that carried the statistics carried the next system
+            if (radius != rspec) {    // gain ratio below 0.937: the elimination was made with another radius
+                if (tm.tid() == 0) {
+                    V.scal[CS_N_MISSES] += 1.0;
+                    V.scal[CS_EXPECT] = CTL_RESOLVED;
+                    V.lmp[0] = radius;
+                    V.lmp[1] = 0.0;
+                }
+            } else {
+                if (tm.tid() == 0) V.scal[CS_N_HITS] += 1.0;
+                tm.sync();
+                ctl_iterate(tm, V);
+            }
+        } else {
+            if (tm.tid() == 0) {
+                V.scal[CS_EXPECT] = CTL_NEW;
+                V.lmp[0] = radius;
+                V.lmp[1] = 0.0;
+            }
+        }
+    } else {
+        if (tm.tid() == 0) {
+            V.scal[CS_N_REJECTED] += 1.0;
+            const double radius = V.scal[CS_RADIUS] / V.scal[CS_DECREASE];
+            V.scal[CS_RADIUS] = radius;
+            V.scal[CS_DECREASE] *= 2.0;
+            V.scal[CS_PLAIN_NEXT] = 1.0;
+            V.scal[CS_EXPECT] = CTL_RESOLVED;
+            V.lmp[0] = radius;
+            V.lmp[1] = 0.0;
+        }
+    }
+}
+
+// One invocation of the controller, right behind an exchange:
+//   CTL_NEW       the pack holds a new linearisation at the current point (first != 0: the start point)
+//   CTL_RESOLVED  the pack holds a re-elimination of the current linearisation [nfail | S | g]
+//   CTL_STEP      the pack holds the statistics of the pending trial step (step_spec != 0: and the system linearised there)
+//   CTL_LS_DONE   the host ran Ceres' line search on the pending step and left its result in CS_LS_*
+// An invocation whose mode is not the one the controller expects (the host queued it ahead of a decision that turned out
+// otherwise) changes nothing.  Publishes the control record at the end.
+template <class TM>
+CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
+    const bool in_turn = V.scal[CS_TERM] < 0.0 && static_cast<int>(V.scal[CS_EXPECT]) == mode &&
+                         (mode != CTL_STEP || (V.scal[CS_STEP_SPEC] != 0.0) == (flag != 0));
+    tm.sync();
+    if (tm.tid() == 0) {
+        V.scal[CS_SEQ] += 1.0;
+        if (in_turn) { V.scal[CS_ACCEPT] = 0.0; V.scal[CS_WILL_END] = 0.0; }
+        else V.scal[CS_N_WASTED] += 1.0;
+    }
+    tm.sync();
+    if (in_turn) {
+        if (mode == CTL_NEW) {
+            ctl_adopt(tm, V, flag != 0);
+            if (flag != 0) {
+                if (tm.tid() == 0) V.scal[CS_INITIAL_COST] = V.scal[CS_COST];
+                tm.sync();
+                if (V.scal[CS_GMAX] <= V.eps) ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_GRADIENT);
+                else ctl_iterate(tm, V);
+            } else {
+                ctl_iterate(tm, V);
+            }
+        } else if (mode == CTL_RESOLVED) {
+            if (tm.tid() == 0) V.scal[CS_NFAIL] = floor(V.pack[V.off_nfail] + 0.5);
+            tm.sync();
+            ctl_iterate(tm, V);
+        } else {  // CTL_STEP, CTL_LS_DONE
+            const double* st = V.pack + V.off_stats;
+            const bool speculated = mode == CTL_STEP && flag != 0;
+            const double gd = st[0] + V.scal[CS_GD_SH], dHd = st[1] + V.scal[CS_DHD_SH];  // PackLayout::GD, DHD
+            double model_change = mode == CTL_STEP ? -gd - 0.5 * dHd : V.scal[CS_MODEL_CHANGE];
+            const bool valid = model_change > 0.0 && ctl_finite(model_change);
+            double cand = st[4], step2 = st[2] + V.scal[CS_STEP2_SH], xnorm2 = st[3] + V.scal[CS_XNORM2_SH];
+            if (mode == CTL_LS_DONE) {
+                cand = V.scal[CS_LS_COST];
+                step2 = V.scal[CS_LS_STEP2] + V.scal[CS_LS_STEP2_SH];
+                xnorm2 = V.scal[CS_LS_XNORM2] + V.scal[CS_LS_XNORM2_SH];
+            }
+            tm.sync();
+            if (tm.tid() == 0 && speculated) V.scal[CS_N_SPEC] += 1.0;
+            if (!valid) {
+                ctl_invalid_step(tm, V);
+            } else if (mode == CTL_STEP && V.constrained && V.line_search && !(ctl_finite(cand) && cand <= V.scal[CS_COST] + 1e-4 * gd)) {
+                // Ceres' projected line search on a bounds-constrained problem (line_search.hpp): the trial point just evaluated is
+                // its first sample and fails the Armijo test.  The search (a handful of samples, rare) is run by the host.
+                if (tm.tid() == 0) {
+                    V.scal[CS_MODEL_CHANGE] = model_change;
+                    V.scal[CS_SLOPE0] = gd;
+                    V.scal[CS_EXPECT] = CTL_LINE_SEARCH;
+                }
+            } else {
+                ctl_decide(tm, V, speculated, model_change, cand, step2, xnorm2);
+            }
+        }
+        tm.sync();
+        if (tm.tid() == 0 && static_cast<int>(V.scal[CS_EXPECT]) == CTL_RESOLVED && V.scal[CS_TERM] < 0.0) {
+            // what follows the re-elimination is known now (its result does not enter the loop-top tests): the host may queue it
+            // behind the re-elimination without waiting for this record's successor
+            int msg;
+            V.scal[CS_WILL_END] = ctl_top_tests(V, &msg) ? 1.0 : 0.0;
+            V.scal[CS_STEP_SPEC] = ctl_next_step_speculative(V) ? 1.0 : 0.0;
+        }
+    }
+    tm.sync();
+    if (tm.tid() == 0) tm.publish(V);
+}
+
+// the control scalars at the start of a solve
+inline void ctl_reset(double* scal) {
+    for (int k = 0; k < CS_COUNT; ++k) scal[k] = 0.0;
+    scal[CS_TERM] = -1.0;
+    scal[CS_MSG] = CM_NONE;
+    scal[CS_EXPECT] = CTL_NEW;
+    scal[CS_RADIUS] = 1e4;
+    scal[CS_DECREASE] = 2.0;
+}
+
+}  // namespace cba

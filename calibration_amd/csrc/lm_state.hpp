@@ -1,6 +1,7 @@
 // lm_state.hpp — device-side LM / Schur state behind an Engine (backend_hip.hip builds it; resident_lm.hip reads it).
 #pragma once
 #include "engine.hpp"
+#include "lm_ctl.hpp"
 #include "schur_math.hpp"
 #include "structure.hpp"
 
@@ -59,6 +60,16 @@ struct HipLMState {
     DevBuf<double> res_Hcc, res_Ssch, res_out;
     PinnedBuf<double> pin_res;
     PinnedBuf<int8_t> pin_mask;
+    // LM controller (lm_ctl.hpp / lm_ctl.hip): the reduced system, the control scalars and the radius of the next elimination
+    // live in device memory; the controller publishes its control record into page-locked host memory
+    DevBuf<double> ctl_buf;     // [scal CS_COUNT | lmp 8 | Hcc n*n | gc n | scale2 n | xs n | rdiag n | x_tmp pk_size | A (n+1)*lda (n > CTL_LDS_MAX_N)]
+    DevBuf<int32_t> ctl_idx;
+    DevBuf<int8_t> ctl_eff;
+    PinnedBuf<double> ctl_rec;  // [control record CS_COUNT | staging of the scalars CS_COUNT | staging of the start point pk_size]
+    CtlView ctl_view{};
+    int ctl_n = -1;             // reduced size the buffers above were laid out for
+    int ctl_poll_us = 400;      // how long ctl_wait polls the record before it sleeps on the stream
+    int lm_ctl_mode = 1;        // 1 = the controller form of the host-driven iteration (default), 0 = the host-side form (CBA_LM_CTL)
 };
 
 
@@ -70,5 +81,10 @@ void resident_lm_warm(Engine& e);
 // false: a step of a bounds-constrained problem needs Ceres' line search (line_search.hpp) — nothing was changed, the caller runs
 // the host-driven iteration instead
 bool resident_lm_solve(Engine& e, const cba_options& o, cba_summary* out, bool keep_parameters = false);
+
+// lm_ctl.hip: one invocation of the controller as a single workgroup on `stream`
+void launch_lm_ctl(const CtlView& V, int mode, int flag, hipStream_t stream);
+bool lm_ctl_fits_lds(int n);
+void warm_lm_ctl();
 
 }  // namespace cba

@@ -224,6 +224,10 @@ struct CpuBackend final : Backend {
     std::vector<double> alt_acc, alt_w;
     bool sys_step(const double* delta_sh, double hub, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
                   int rank, double* pack) override {
+        return sys_step_at(delta_sh, hub, radius_next, constrained, L, ar, rank, pack);
+    }
+    bool sys_step_at(const double* delta_sh, double hub, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
+                     int rank, double* pack) {
         std::fill(pack, pack + L.size, 0.0);
         for (int v = 0; v < s.n_views; ++v) {
             const int nb = static_cast<int>(s.link_off[v + 1] - s.link_off[v]);
@@ -249,7 +253,7 @@ struct CpuBackend final : Backend {
         std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
         pack[L.cost] = cost2[0];
         pack[L.nfail] = nf;
-        std::copy(S.begin(), S.end(), pack + L.S);
+        L.pack_S(S, pack + L.S);
         std::copy(g.begin(), g.end(), pack + L.g);
         pack[L.gmax + rank] = gm;
         ar(pack, L.size);
@@ -292,6 +296,128 @@ struct CpuBackend final : Backend {
     }
     void download_private(double* vp) override { std::memcpy(vp, view[0].data(), sizeof(double) * view[0].size()); }
     void download_blocks(std::vector<double>& acc, std::vector<double>& w) override { acc = blk_acc; w = blk_w; }
+
+    // ---- the controller form of the iteration: lm_ctl.hpp run by a team of one host thread -----------------------------------
+    struct Ctl {
+        std::vector<double> scal, Hcc, gc, scale2, xs, rdiag, Dk, x[3], A, pack, rec;
+        std::vector<int8_t> eff, active, cam_var;
+        std::vector<int> idx;
+        double lmp[2] = {1e4, 1.0};
+        CtlView V;
+        bool constrained = false;
+    } ctl;
+    bool use_ctl = true;
+    void ctl_sync_params() {  // the controller's packs -> the per-copy arrays the evaluation reads
+        for (int k = 0; k < 2; ++k) {
+            std::memcpy(intr[k].data(), ctl.x[k].data(), sizeof(double) * intr[k].size());
+            std::memcpy(cam[k].data(), ctl.x[k].data() + ctl.V.pk_cam, sizeof(double) * cam[k].size());
+            std::memcpy(target[k].data(), ctl.x[k].data() + ctl.V.pk_target, sizeof(double) * 7);
+        }
+    }
+    void ctl_invoke(int mode, int flag) {
+        SerialTeam tm;
+        ctl_run(tm, ctl.V, mode, flag);
+    }
+    bool ctl_begin(const CtlSetup& cs, const PackLayout& L) override {
+        if (!use_ctl) return false;
+        const int n = s.nsh;
+        CtlView& V = ctl.V;
+        V.n = n; V.n_cams = s.n_cams; V.PI = s.PI; V.PL = s.PL; V.NH = s.NH; V.NACC = s.NACC; V.PC = s.PC; V.sh_base = s.sh_base;
+        V.chain = s.chain; V.n_ranks = L.n_ranks;
+        V.off_stats = L.stats; V.off_cam = L.cam; V.off_cost = L.cost; V.off_nfail = L.nfail; V.off_S = L.S; V.off_g = L.g; V.off_gmax = L.gmax;
+        V.eps = cs.eps; V.max_iterations = cs.max_iterations; V.constrained = cs.constrained; V.line_search = cs.line_search;
+        V.speculate = cs.speculate; V.intr_var = cs.intr_var; V.target_var = cs.target_var;
+        V.pk_cam = static_cast<int64_t>(intr[0].size()); V.pk_target = V.pk_cam + static_cast<int64_t>(cam[0].size()); V.pk_delta = V.pk_target + 7;
+        ctl.constrained = cs.constrained;
+        ctl.scal.assign(CS_COUNT, 0.0); ctl.rec.assign(CS_COUNT, 0.0);
+        ctl_reset(ctl.scal.data());
+        ctl.Hcc.assign(static_cast<size_t>(n) * n, 0.0); ctl.gc.assign(n, 0.0); ctl.scale2.assign(n, 1.0); ctl.xs.assign(n, 0.0);
+        ctl.rdiag.assign(n, 0.0); ctl.Dk.assign(CTL_NB * CTL_NB, 0.0);
+        for (int k = 0; k < 3; ++k) ctl.x[k].assign(static_cast<size_t>(V.pk_delta) + n, 0.0);
+        V.lda = n | 1;
+        ctl.A.assign(static_cast<size_t>(n + 1) * V.lda, 0.0);
+        ctl.pack.assign(static_cast<size_t>(L.size), 0.0);
+        ctl.eff.assign(n, 0); ctl.idx.assign(n, 0);
+        ctl.active.assign(cs.active->begin(), cs.active->end());
+        ctl.cam_var.assign(cs.cam_var->begin(), cs.cam_var->end());
+        std::memcpy(ctl.x[0].data(), cs.intr, sizeof(double) * intr[0].size());
+        if (s.chain != CBA_CHAIN_INTRINSIC) std::memcpy(ctl.x[0].data() + V.pk_cam, cs.cam, sizeof(double) * cam[0].size());
+        if (s.chain == CBA_CHAIN_BUNDLE) std::memcpy(ctl.x[0].data() + V.pk_target, cs.target, sizeof(double) * 7);
+        ctl.x[1] = ctl.x[0];
+        ctl.lmp[0] = 1e4; ctl.lmp[1] = 1.0;
+        V.x_cur = ctl.x[0].data(); V.x_trial = ctl.x[1].data(); V.x_tmp = ctl.x[2].data();
+        V.scal = ctl.scal.data(); V.pack = ctl.pack.data(); V.Hcc = ctl.Hcc.data(); V.gc = ctl.gc.data(); V.scale2 = ctl.scale2.data();
+        V.eff = ctl.eff.data(); V.active = ctl.active.data(); V.cam_var = ctl.cam_var.data(); V.idx = ctl.idx.data();
+        V.A = ctl.A.data(); V.rdiag = ctl.rdiag.data(); V.xs = ctl.xs.data(); V.Dk = ctl.Dk.data(); V.lmp = ctl.lmp; V.rec = ctl.rec.data();
+        return true;
+    }
+    void ctl_new(double hub, bool first, const PackLayout& L, const AllReduce& ar, int rank) override {
+        ctl_sync_params();
+        std::vector<double> cam_acc, S, g;
+        double cost2[2] = {0, 0}, gm = 0;
+        int nf = 0;
+        normal_eq_at(0, hub, cam_acc, cost2);
+        schur_at(0, ctl.lmp[0], ctl.lmp[1] != 0.0, ctl.constrained, S, g, &gm, &nf);
+        double* pack = ctl.pack.data();
+        std::fill(pack, pack + L.size, 0.0);
+        std::copy(cam_acc.begin(), cam_acc.end(), pack + L.cam);
+        pack[L.cost] = cost2[0];
+        pack[L.nfail] = nf;
+        L.pack_S(S, pack + L.S);
+        std::copy(g.begin(), g.end(), pack + L.g);
+        pack[L.gmax + rank] = gm;
+        ar(pack + L.cam, L.size - L.cam);
+        ctl_invoke(CTL_NEW, first ? 1 : 0);
+    }
+    void ctl_resolve(const PackLayout& L, const AllReduce& ar, int rank) override {
+        (void)rank;
+        std::vector<double> S, g;
+        double gm = 0;
+        int nf = 0;
+        schur_at(0, ctl.lmp[0], false, ctl.constrained, S, g, &gm, &nf);
+        double* pack = ctl.pack.data();
+        pack[L.nfail] = nf;
+        L.pack_S(S, pack + L.S);
+        std::copy(g.begin(), g.end(), pack + L.g);
+        ar(pack + L.nfail, L.gmax - L.nfail);
+        ctl_invoke(CTL_RESOLVED, 0);
+    }
+    void ctl_step(double hub, bool speculative, const PackLayout& L, const AllReduce& ar, int rank) override {
+        ctl_sync_params();
+        const double* delta_sh = ctl.x[1].data() + ctl.V.pk_delta;
+        if (speculative) {
+            sys_step_at(delta_sh, hub, ctl.lmp[0], ctl.constrained, L, ar, rank, ctl.pack.data());
+        } else {
+            TrialStats st;
+            trial(delta_sh, hub, &st);
+            double* pack = ctl.pack.data();
+            for (int k = 0; k < 6; ++k) pack[L.stats + k] = 0.0;
+            pack[L.stats + PackLayout::GD] = st.gd; pack[L.stats + PackLayout::DHD] = st.dHd;
+            pack[L.stats + PackLayout::STEP2] = st.step2; pack[L.stats + PackLayout::XNORM2] = st.xnorm2;
+            pack[L.stats + PackLayout::TRIAL_COST] = st.cost;
+            ar(pack + L.stats, 6);
+        }
+        ctl_invoke(CTL_STEP, speculative ? 1 : 0);
+    }
+    void ctl_accept(bool blocks) override {
+        view[0] = view[1];
+        if (blocks) { blk_acc = alt_acc; blk_w = alt_w; }
+    }
+    const double* ctl_wait() override { return ctl.rec.data(); }
+    void ctl_fetch(double* i, double* c, double* t, double* delta) override {
+        std::memcpy(i, ctl.x[0].data(), sizeof(double) * intr[0].size());
+        if (s.chain != CBA_CHAIN_INTRINSIC) std::memcpy(c, ctl.x[0].data() + ctl.V.pk_cam, sizeof(double) * cam[0].size());
+        if (s.chain == CBA_CHAIN_BUNDLE) std::memcpy(t, ctl.x[0].data() + ctl.V.pk_target, sizeof(double) * 7);
+        std::memcpy(delta, ctl.x[1].data() + ctl.V.pk_delta, sizeof(double) * s.nsh);
+    }
+    void ctl_line_search_done(const double* scal) override {
+        // the last sample's shared blocks (upload_shared(1, ...)) are the trial point the decision is about
+        std::memcpy(ctl.x[1].data(), intr[1].data(), sizeof(double) * intr[1].size());
+        std::memcpy(ctl.x[1].data() + ctl.V.pk_cam, cam[1].data(), sizeof(double) * cam[1].size());
+        std::memcpy(ctl.x[1].data() + ctl.V.pk_target, target[1].data(), sizeof(double) * 7);
+        std::memcpy(ctl.scal.data(), scal, sizeof(double) * CS_COUNT);
+        ctl_invoke(CTL_LS_DONE, 0);
+    }
 };
 
 struct Session {
@@ -335,12 +461,14 @@ const char* hm_last_error(void) { return g_err.c_str(); }
 // speculate: 1 / 0 = linearise trial points ahead of the accept decision or not, -1 = the driver's default (CBA_LM_SPECULATE)
 // stats8 (may be NULL) = {all-reduce calls, all-reduced doubles, speculative steps, hits, misses, rejected steps, line searches,
 // line-search evaluations}
-int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
-                       int speculate, cba_summary* out, int64_t* stats8) {
+// controller: 1 = the controller form of the iteration (lm_ctl.hpp, what libcalibba runs), 0 = the host-side form, -1 = default
+int hm_reproj_solve_mode(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
+                         int speculate, int controller, cba_summary* out, int64_t* stats8) {
     return guarded([&] {
         Session ss;
         load(*d, ss);
         CpuBackend be(ss.s, *d, ss.view);
+        if (controller >= 0) be.use_ctl = controller != 0;
         AllReduce ar = [&](double* buf, int64_t n) {
             if (fn && fn(buf, n, user) != 0) throw std::runtime_error("allreduce callback failed");
         };
@@ -355,6 +483,10 @@ int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_al
             stats8[6] = x.line_searches; stats8[7] = x.line_search_evaluations;
         }
     });
+}
+int hm_reproj_solve_ex(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
+                       int speculate, cba_summary* out, int64_t* stats8) {
+    return hm_reproj_solve_mode(d, o, fn, user, n_ranks, rank, speculate, -1, out, stats8);
 }
 int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allreduce_fn fn, void* user, int n_ranks, int rank,
                     cba_summary* out) {
