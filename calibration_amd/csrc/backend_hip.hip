@@ -26,7 +26,7 @@
 namespace cba {
 
 constexpr int VCHUNK = 8;    // views per syrk / gvec workgroup
-constexpr size_t CTL_REC_FETCH = CS_COUNT + 80;  // HipLMState::ctl_rec = [control record | staged scalars + lmp (72) | fetched parameters]
+constexpr size_t CTL_REC_FETCH = 2 * CS_COUNT + 8;  // HipLMState::ctl_rec = [control record | staged scalars + lmp | fetched parameters]
 constexpr int CCHUNK = 16;   // blocks per camera-sum chunk
 
 __global__ void k_weights(int n_blocks, int NACC, int s_idx, const double* __restrict__ blk_acc, double huber_delta,
@@ -904,16 +904,24 @@ struct HipBackend final : Backend {
     void ensure_ctl(const PackLayout& L) {
         const Structure& s = st.s;
         const int n = s.nsh;
-        const int lda = n | 1;
+        const int lda = ctl_lda(n), M8 = ctl_padded(n);
         const bool lds = lm_ctl_fits_lds(n);
-        const size_t o_scal = 0, o_lmp = CS_COUNT, o_Hcc = o_lmp + 8, o_gc = o_Hcc + static_cast<size_t>(n) * n, o_scale2 = o_gc + n,
-                     o_xs = o_scale2 + n, o_rdiag = o_xs + n, o_xtmp = o_rdiag + n, o_A = o_xtmp + e.pk_size,
-                     total = o_A + (lds ? 8 : static_cast<size_t>(n + 1) * lda);
+        const size_t o_scal = 0, o_lmp = CS_COUNT, o_camc = o_lmp + 8, o_gc = o_camc + static_cast<size_t>(s.n_cams) * s.NACC, o_scale2 = o_gc + n,
+                     o_hdiag = o_scale2 + n, o_xs = o_hdiag + n, o_rdiag = o_xs + M8, o_xtmp = o_rdiag + M8, o_Ld = o_xtmp + e.pk_size,
+                     o_A = o_Ld + static_cast<size_t>(M8) * CTL_NB, total = o_A + (lds ? 8 : static_cast<size_t>(M8 + 1) * lda);
         if (st.ctl_n != n || st.ctl_buf.n < total) {
             st.ctl_buf.alloc(total);
             st.ctl_buf.zero(e.stream);
-            st.ctl_idx.alloc(static_cast<size_t>(std::max(1, n)));
+            st.ctl_idx.alloc(static_cast<size_t>(3 * std::max(1, n)));  // [effective columns | column -> camera | column -> local column]
             st.ctl_eff.alloc(static_cast<size_t>(std::max(1, n)));
+            {   // the column tables (structure.hpp shared_col, inverted), once per problem
+                std::vector<int32_t> tab(static_cast<size_t>(3 * std::max(1, n)), 0);
+                CtlView T{};
+                T.chain = s.chain; T.PC = s.PC;
+                for (int i = 0; i < n; ++i) ctl_decode(T, i, &tab[static_cast<size_t>(n) + i], &tab[static_cast<size_t>(2 * n) + i]);
+                st.ctl_idx.upload(tab.data(), tab.size(), e.stream);
+                CBA_HIP(hipStreamSynchronize(e.stream));
+            }
             st.ctl_rec.reserve(CTL_REC_FETCH + e.pk_size + static_cast<size_t>(n) + 8);
             st.ctl_n = n;
         }
@@ -924,10 +932,11 @@ struct HipBackend final : Backend {
         V.pk_cam = static_cast<int64_t>(e.pk_cam); V.pk_target = static_cast<int64_t>(e.pk_target); V.pk_delta = static_cast<int64_t>(e.pk_delta);
         double* b = st.ctl_buf.p;
         V.x_cur = e.shared_pack[0].p; V.x_trial = e.shared_pack[1].p; V.x_tmp = b + o_xtmp;
-        V.scal = b + o_scal; V.lmp = b + o_lmp; V.Hcc = b + o_Hcc; V.gc = b + o_gc; V.scale2 = b + o_scale2; V.xs = b + o_xs;
-        V.rdiag = b + o_rdiag; V.A = b + o_A; V.lda = lda; V.Dk = nullptr;  // (the kernel stages the diagonal block in LDS)
+        V.scal = b + o_scal; V.lmp = b + o_lmp; V.camc = b + o_camc; V.gc = b + o_gc; V.scale2 = b + o_scale2; V.hdiag = b + o_hdiag; V.xs = b + o_xs;
+        V.rdiag = b + o_rdiag; V.A = b + o_A; V.Ld = b + o_Ld; V.lda = lda; V.okflag = nullptr;  // (okflag: LDS, set by the kernel)
         V.pack = st.pack_dev.p;
-        V.eff = st.ctl_eff.p; V.idx = st.ctl_idx.p; V.active = st.res_active.p; V.cam_var = st.res_cam_var.p;
+        V.eff = st.ctl_eff.p; V.idx = st.ctl_idx.p; V.colcam = st.ctl_idx.p + n; V.collc = st.ctl_idx.p + 2 * n;
+        V.active = st.res_active.p; V.cam_var = st.res_cam_var.p;
         V.rec = st.ctl_rec.p;
     }
     void run_ctl(int mode, int flag) {

@@ -356,6 +356,13 @@ class LMDriver {
             std::fprintf(stderr, "[cba timing] solve %.1f us, %d iterations, %d waits: waiting %.1f us, host between a wait and the end of its "
                          "launches %.1f us (%.1f per wait), controller invocations out of turn %d\n", out->solve_seconds * 1e6, iter, n_waits,
                          t_wait, t_queue, t_queue / std::max(1, n_waits), static_cast<int>(rec[CS_N_WASTED]));
+        if (timing && rec[CS_PROF + CP_PUBLISH] > 0.0) {
+            static const char* const names[CTL_NPROF] = {"entry", "adopt", "gradient norm", "assemble", "factorise", "back-substitute", "plus",
+                                                         "model terms", "decide", "publish", "", ""};
+            std::fprintf(stderr, "[cba timing] controller kernel phases, us over %d invocations:", static_cast<int>(rec[CS_SEQ]));
+            for (int k = 0; k <= CP_PUBLISH; ++k) std::fprintf(stderr, " %s %.1f |", names[k], rec[CS_PROF + k] * 0.01);
+            std::fprintf(stderr, "\n");
+        }
         std::snprintf(out->report, sizeof(out->report), "calibba(schur LM, %d rank%s): %s iters=%d cost %.6e -> %.6e", n_ranks_,
                       n_ranks_ > 1 ? "s" : "", ctl_message(static_cast<int>(rec[CS_MSG])), iter, out->initial_cost, cost_);
         return true;

@@ -20,6 +20,12 @@
 #include "reproj_math.hpp"
 #include "schur_math.hpp"
 
+#if defined(__HIPCC__)
+#define CBA_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define CBA_NOINLINE inline
+#endif
+
 namespace cba {
 
 // ---- control scalars (doubles; CtlView::scal, published verbatim as the control record) -----------------------------------
@@ -39,9 +45,12 @@ enum CtlSlot : int {
     CS_P_COST, CS_P_RADIUS, CS_P_GMAX, CS_P_ITER,                // the state a decision was taken in (verbose output)
     CS_N_SPEC, CS_N_HITS, CS_N_MISSES, CS_N_REJECTED, CS_N_WASTED,
     CS_LS_A, CS_LS_COST, CS_LS_STEP2, CS_LS_XNORM2, CS_LS_STEP2_SH, CS_LS_XNORM2_SH,  // host -> controller: result of a line search
-    CS_COUNT = 64
+    CS_PROF,           // [CTL_NPROF] time per phase of the controller kernel, 10 ns ticks summed over the solve (CtlProf)
+    CS_COUNT = 80
 };
-static_assert(CS_LS_XNORM2_SH < CS_COUNT, "control record size");
+constexpr int CTL_NPROF = 12;
+enum CtlProf : int { CP_ENTRY = 0, CP_ADOPT, CP_GMAX, CP_ASSEMBLE, CP_FACTOR, CP_BACKSOLVE, CP_PLUS, CP_MODEL, CP_DECIDE, CP_PUBLISH };
+static_assert(CS_PROF + CTL_NPROF <= CS_COUNT, "control record size");
 
 enum CtlMode : int { CTL_NONE = 0, CTL_NEW = 1, CTL_RESOLVED = 2, CTL_STEP = 3, CTL_LS_DONE = 4, CTL_LINE_SEARCH = 5 };
 enum CtlMsg : int { CM_GRADIENT = 0, CM_MAX_ITER, CM_MIN_RADIUS, CM_INVALID_STEPS, CM_PARAMETER, CM_FUNCTION, CM_NONE };
@@ -53,6 +62,8 @@ inline const char* ctl_message(int m) {
 }
 
 constexpr int CTL_NB = 8;  // panel width of the blocked factorisation
+CBA_HD int ctl_padded(int n) { return (n + CTL_NB - 1) / CTL_NB * CTL_NB; }  // rows of the padded reduced matrix
+CBA_HD int ctl_lda(int n) { return ctl_padded(n) | 1; }                        // its row stride (odd: conflict-free column walks in LDS)
 constexpr int CTL_LDS_MAX_N = 128;  // the GPU controller keeps the reduced matrix in LDS up to this size (129 x 129 doubles = 133 KB)
 
 // Everything the controller touches, as raw pointers (device memory on the GPU, host vectors in the CPU test build).
@@ -70,14 +81,18 @@ struct CtlView {
     // state
     double* scal;          // [CS_COUNT]
     const double* pack;    // the all-reduced pack of the exchange this invocation follows
-    double *Hcc, *gc, *scale2;
+    double* camc;          // [n_cams][NACC] the CURRENT linearisation's per-camera sums: H_cc (block-sparse) is read from them in place
+    double *gc, *scale2, *hdiag;  // g_c, Jacobi scale^2, diag(H_cc)  [n]
+    const int *colcam, *collc;    // shared column -> (camera or -1 for the bundle chain's target pose, local tangent column)
     int8_t* eff;
     const int8_t *active, *cam_var;
     int* idx;              // effective columns, compact
     // work
-    double* A;             // (m + 1) x lda: reduced matrix -> its lower factor; row m carries the right-hand side
+    double* A;             // (M + 1) x lda, M = m rounded up to CTL_NB, lda >= M: reduced matrix -> the panels of its lower factor;
+                           // row M carries the right-hand side
     int lda;
-    double *rdiag, *xs, *Dk;  // reciprocal pivots [n], solution in compact order [n], staged diagonal block [NB * NB]
+    double *rdiag, *xs, *Ld;  // reciprocal pivots, solution in compact order [n rounded up to CTL_NB], factors of the diagonal blocks [n / NB][NB * NB]
+    int* okflag;           // the factorisation's pivot test, from the thread that took it to the team
     double* lmp;           // [radius of the next elimination, init_scale]: read by the per-view elimination kernels
     double* rec;           // where the control record is published (page-locked host memory on the GPU)
 };
@@ -88,6 +103,8 @@ struct SerialTeam {
     CBA_HD void sync() const {}
     CBA_HD double sum(double v) const { return v; }
     CBA_HD double max(double v) const { return v; }
+    CBA_HD void tick(const CtlView&, int) const {}
+    CBA_HD void mark(int) const {}
     CBA_HD void publish(const CtlView& V) const {
         for (int k = 1; k < CS_COUNT; ++k) V.rec[k] = V.scal[k];
         V.rec[CS_SEQ] = V.scal[CS_SEQ];
@@ -115,8 +132,9 @@ CBA_HD int64_t ctl_sidx(int n, int i, int j) { return i <= j ? static_cast<int64
 
 // Plus on the shared blocks with the fx, fy >= 0 projection (LMDriver::shared_plus): xo = Plus(x, delta); the team's totals of
 // |xo - x|^2 and |x|^2 over the variable blocks.  xo is complete for every thread on return.
+// (used for the gradient norm and for the trial point: NOT inlined, so that the quaternion update's sin / cos exist once in the code)
 template <class TM>
-CBA_HD void ctl_plus(TM& tm, const CtlView& V, const double* x, const double* delta, double* xo, double* step2, double* xnorm2) {
+CBA_NOINLINE void ctl_plus(TM& tm, const CtlView& V, const double* x, const double* delta, double* xo, double* step2, double* xnorm2) {
     double s2 = 0.0, x2 = 0.0;
     const int PI = V.PI;
     for (int i = tm.tid(); i < V.n_cams * PI; i += tm.size()) {
@@ -180,39 +198,46 @@ CBA_HD double ctl_shared_gmax(TM& tm, const CtlView& V) {
 
 // The pack holds an all-reduced linearisation (a new system, or an accepted speculative step): make it the current one
 // (LMDriver::adopt_system): H_cc, g_c from the per-camera sums, effective columns, Jacobi scale (first system), cost, gradient norm.
+// local tangent column lc of a block of camera c -> global shared column (-1: a private pose column); structure.hpp shared_col
+CBA_HD int ctl_shared_col(const CtlView& V, int c, int lc) {
+    if (V.chain == CH_BUNDLE) return lc < 6 ? lc : V.sh_base + c * V.PC + (lc - 6);
+    return lc < 6 ? -1 : c * V.PC + (lc - 6);
+}
+
+// H_cc[i][j] from per-camera sums: zero unless both columns belong to one camera (or to the target pose, which every camera's
+// blocks see: summed in camera order)
+CBA_HD double ctl_hcc(const CtlView& V, const double* cam, int i, int j) {
+    const int ci = V.colcam[i], cj = V.colcam[j];
+    const int h = hidx_sym(V.PL, V.collc[i], V.collc[j]);
+    if (ci < 0 && cj < 0) {
+        double v = 0.0;
+        for (int c = 0; c < V.n_cams; ++c) v += cam[static_cast<int64_t>(c) * V.NACC + h];
+        return v;
+    }
+    if (ci < 0 || cj < 0 || ci == cj) return cam[static_cast<int64_t>(ci < 0 ? cj : ci) * V.NACC + h];
+    return 0.0;
+}
+CBA_HD double ctl_gc(const CtlView& V, const double* cam, int i) {
+    const int ci = V.colcam[i], li = V.collc[i];
+    if (ci < 0) {
+        double v = 0.0;
+        for (int c = 0; c < V.n_cams; ++c) v += cam[static_cast<int64_t>(c) * V.NACC + V.NH + li];
+        return v;
+    }
+    return cam[static_cast<int64_t>(ci) * V.NACC + V.NH + li];
+}
+
 template <class TM>
 CBA_HD void ctl_adopt(TM& tm, const CtlView& V, bool init_scale) {
-    const int n = V.n, PL = V.PL, NACC = V.NACC, NH = V.NH;
+    const int n = V.n;
     const double* cam_acc = V.pack + V.off_cam;
-    for (int e = tm.tid(); e < n * n + n; e += tm.size()) {
-        if (e < n * n) {
-            const int i = e / n, j = e - i * n;
-            int ci, li, cj, lj;
-            ctl_decode(V, i, &ci, &li);
-            ctl_decode(V, j, &cj, &lj);
-            double h = 0.0;
-            if (ci < 0 && cj < 0) {
-                for (int c = 0; c < V.n_cams; ++c) h += cam_acc[static_cast<int64_t>(c) * NACC + hidx_sym(PL, li, lj)];
-            } else if (ci < 0 || cj < 0 || ci == cj) {
-                h = cam_acc[static_cast<int64_t>(ci < 0 ? cj : ci) * NACC + hidx_sym(PL, li, lj)];
-            }
-            V.Hcc[e] = h;
-        } else {
-            const int i = e - n * n;
-            int ci, li;
-            ctl_decode(V, i, &ci, &li);
-            double g = 0.0;
-            if (ci < 0) {
-                for (int c = 0; c < V.n_cams; ++c) g += cam_acc[static_cast<int64_t>(c) * NACC + NH + li];
-            } else {
-                g = cam_acc[static_cast<int64_t>(ci) * NACC + NH + li];
-            }
-            V.gc[i] = g;
-        }
-    }
-    tm.sync();
+    // the per-camera sums become the controller's own copy: a speculative step that is rejected later leaves the pack holding the
+    // trial point's system, and the current H_cc must survive it (H_cc is never formed: n_cams * NACC numbers instead of n^2)
+    for (int e = tm.tid(); e < V.n_cams * V.NACC; e += tm.size()) V.camc[e] = cam_acc[e];
     for (int i = tm.tid(); i < n; i += tm.size()) {
-        const double hii = V.Hcc[static_cast<int64_t>(i) * n + i];
+        const double hii = ctl_hcc(V, cam_acc, i, i);
+        V.hdiag[i] = hii;
+        V.gc[i] = ctl_gc(V, cam_acc, i);
         V.eff[i] = V.active[i] && hii != 0.0;  // columns nobody observes behave like constant blocks
         if (init_scale) {
             const double sc = 1.0 / (1.0 + sqrt(hii));
@@ -232,147 +257,217 @@ CBA_HD void ctl_adopt(TM& tm, const CtlView& V, bool init_scale) {
         V.scal[CS_GMAX_PRIV] = gm;
     }
     tm.sync();
+    tm.tick(V, CP_ADOPT);
     const double gsh = ctl_shared_gmax(tm, V);
     if (tm.tid() == 0) V.scal[CS_GMAX] = fmax(V.scal[CS_GMAX_PRIV], gsh);
     tm.sync();
+    tm.tick(V, CP_GMAX);
 }
 
 // ---- the reduced solve ---------------------------------------------------------------------------------------------------
-// In-place blocked right-looking Cholesky of the leading m x m block of A (lower, row-major, stride lda) with panels of CTL_NB
-// columns; row m of A is carried along as one more panel row, so that it leaves as L^-1 b (the forward substitution costs no
-// extra pass).  Per panel: every thread factorises the staged CTL_NB x CTL_NB diagonal block in registers (redundantly: it is a
-// latency chain, not work, and it makes the pivot test team-uniform without a broadcast), the threads owning a row write that
-// row of L / forward-substitute their panel entries, barrier, then the whole team updates the trailing matrix in 4 x 4 tiles,
-// barrier.  Dk receives the next diagonal block while it is updated.  rdiag[k] = 1 / L[k][k].  Returns false (uniformly) if a
-// pivot is not positive and finite.
+// sqrt(d) and 1 / sqrt(d) of a pivot.  On the GPU: v_rsq_f64 and two coupled Newton steps (a dozen dependent instructions; the
+// library sqrt followed by a division is ~40, and the pivots are THE dependent chain of the factorisation).
+CBA_HD void ctl_sqrt_rsqrt(double d, double* sq, double* rsq) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double e = __builtin_fma(-g, g, d);
+    g = __builtin_fma(e, h, g);
+    *sq = g;
+    *rsq = 2.0 * h;
+#else
+    const double s = sqrt(d);
+    *sq = s;
+    *rsq = 1.0 / s;
+#endif
+}
+
+// Blocked right-looking Cholesky of the M x M matrix in A (lower triangle, row-major, stride lda; M a multiple of CTL_NB: the
+// caller pads with identity rows) with panels of CTL_NB columns.  Row M of A carries the right-hand side along as one more panel
+// row, so that it leaves as L^-1 b (the forward substitution costs no extra pass).  The factor of the p-th diagonal block goes to
+// Ld[p] (CTL_NB x CTL_NB, lower; its upper entries are scratch), the panel entries below it stay in A; rdiag[k] = 1 / L[k][k].
+// Per panel: every thread that owns a row i >= k0 reads the diagonal block, factorises it in registers (each for itself: a
+// latency chain, not work, and nobody waits for a broadcast) and forward-substitutes its own row against it - a row of the
+// diagonal block comes out as its row of L, by the same arithmetic; barrier; the team updates the trailing matrix in 4 x 4 tiles
+// whose rows and columns are INTERLEAVED (tile (ti, tj) = rows ti + a nt, columns tj + b nt: neighbouring threads touch
+// neighbouring rows, conflict-free in LDS with an odd stride; a tile with ti > tj holds 16 distinct unordered pairs, a diagonal
+// one writes its mirrored half into the unused upper triangle), other threads the right-hand-side row; barrier.
+// Written without guards (padding instead) and with 32-bit offsets: for ONE workgroup the cost is the instruction count along
+// the chain panel -> barrier -> tile -> barrier, measured at 4-5 cycles per instruction (tools/probe/ctl_probe.hip).
+// *okflag / the return value: every pivot positive and finite.
 template <class TM>
-CBA_HD bool ctl_cholesky(TM& tm, double* A, int lda, int m, double* Dk, double* rdiag) {
+CBA_HD bool ctl_cholesky(TM& tm, double* A, int lda, int M, double* Ld, double* rdiag, int* okflag) {
     constexpr int NB = CTL_NB;
-    for (int k0 = 0; k0 < m; k0 += NB) {
-        const int nb = m - k0 < NB ? m - k0 : NB;
-        // --- diagonal block (staged in Dk, lower; identity beyond nb) ---
-        double L[NB][NB], inv[NB];
+    for (int k0 = 0, p = 0; k0 < M; k0 += NB, ++p) {
+        tm.mark(0);
+        const int b0 = k0 + NB;
+        if (k0 + tm.tid() <= M) {  // this thread owns a panel row (thread 0 always does)
+            double L[NB][NB], inv[NB];
+            const double* Dg = A + k0 * lda + k0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) L[i][j] = (i < nb && j < nb) ? Dk[i * NB + j] : (i == j ? 1.0 : 0.0);
-        bool ok = true;
+                for (int j = 0; j <= i; ++j) L[i][j] = Dg[i * lda + j];
+            bool ok = true;
+            tm.mark(1);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            double d = L[j][j];
+            for (int j = 0; j < NB; ++j) {
+                double d = L[j][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-            if (!(d > 0.0) || !ctl_finite(d)) ok = false;
-            const double r = 1.0 / sqrt(d);
-            inv[j] = r;
-            L[j][j] = d * r;
+                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+                if (!(d > 0.0) || !ctl_finite(d)) ok = false;
+                double sq, r;
+                ctl_sqrt_rsqrt(d, &sq, &r);
+                inv[j] = r;
+                L[j][j] = sq;
 #pragma unroll
-            for (int i = j + 1; i < NB; ++i) {
-                double s = L[i][j];
+                for (int i = j + 1; i < NB; ++i) {
+                    double s = L[i][j];
 #pragma unroll
-                for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-                L[i][j] = s * r;
+                    for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+                    L[i][j] = s * r;
+                }
             }
-        }
-        if (!ok) return false;  // every thread saw the same numbers
-        // --- panel rows: row i of [k0, m] ---
-        for (int i = k0 + tm.tid(); i <= m; i += tm.size()) {
-            double* row = A + static_cast<int64_t>(i) * lda + k0;
-            if (i < k0 + nb) {  // a row of the diagonal block (static register indices: r is matched, not used as an index)
+            if (tm.tid() == 0) {
+                *okflag = ok ? 1 : 0;
 #pragma unroll
-                for (int r = 0; r < NB; ++r)
-                    if (i - k0 == r) {
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) row[c] = L[r][c];
-                        rdiag[i] = inv[r];
-                    }
-            } else {
+                for (int c = 0; c < NB; ++c) rdiag[k0 + c] = inv[c];
+            }
+            tm.mark(2);
+            for (int i = k0 + tm.tid(); i <= M; i += tm.size()) {
+                double* row = A + i * lda + k0;
                 double x[NB];
 #pragma unroll
+                for (int c = 0; c < NB; ++c) x[c] = row[c];
+#pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    double s = c < nb ? row[c] : 0.0;
+                    double sacc = x[c];
 #pragma unroll
-                    for (int k = 0; k < c; ++k) s -= x[k] * L[c][k];
-                    x[c] = s * inv[c];
+                    for (int k = 0; k < c; ++k) sacc -= x[k] * L[c][k];
+                    x[c] = sacc * inv[c];
                 }
+                double* dst = i < b0 ? Ld + (p * NB + (i - k0)) * NB : row;  // a row of the diagonal block is its row of L
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    if (c < nb) row[c] = x[c];
+                for (int c = 0; c < NB; ++c) dst[c] = x[c];
             }
         }
+        tm.mark(3);
         tm.sync();
-        // --- trailing update: A[i][j] -= sum_c A[i][k0 + c] A[j][k0 + c], k0 + nb <= j <= i <= m (row m: j < m), 4 x 4 tiles ---
-        const int b0 = k0 + nb;
-        if (b0 <= m) {
-            const int nrows = m + 1 - b0;  // rows b0 .. m
-            const int nt = (nrows + 3) >> 2;
+        tm.mark(4);
+        if (!*okflag) return false;
+        const int nr = M - b0;  // trailing rows b0 .. M - 1 (a multiple of NB), then the right-hand-side row M
+        if (nr > 0) {
+            const int nt = nr >> 2;
             const int ntiles = nt * (nt + 1) / 2;
-            for (int t = tm.tid(); t < ntiles; t += tm.size()) {
-                int ti = static_cast<int>((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-                while (ti * (ti + 1) / 2 > t) --ti;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                const int i0 = b0 + 4 * ti, j0 = b0 + 4 * tj;
-                double pi[4][NB], pj[4][NB];
+            for (int t = tm.tid(); t < ntiles + nr; t += tm.size()) {
+                if (t < ntiles) {
+                    int ti = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
+                    ti += ((ti + 1) * (ti + 2) / 2 <= t) ? 1 : 0;
+                    ti -= (ti * (ti + 1) / 2 > t) ? 1 : 0;
+                    const int tj = t - ti * (ti + 1) / 2;
+                    const int ri = (b0 + ti) * lda, rj = (b0 + tj) * lda, st = nt * lda;  // row offsets of a = 0 and the row step
+                    double pi[4][NB], pj[4][NB], av[4][4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        pi[a][c] = (i0 + a <= m && c < nb) ? A[static_cast<int64_t>(i0 + a) * lda + k0 + c] : 0.0;
-                        pj[a][c] = (j0 + a < m && c < nb) ? A[static_cast<int64_t>(j0 + a) * lda + k0 + c] : 0.0;
-                    }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int i = i0 + a, j = j0 + b;
-                        if (i <= m && j <= i && j < m) {
-                            double s = A[static_cast<int64_t>(i) * lda + j];
-#pragma unroll
-                            for (int c = 0; c < NB; ++c) s -= pi[a][c] * pj[b][c];
-                            A[static_cast<int64_t>(i) * lda + j] = s;
-                            if (i < b0 + NB && i < m) Dk[(i - b0) * NB + (j - b0)] = s;  // the next diagonal block
+                        for (int c = 0; c < NB; ++c) {
+                            pi[a][c] = A[ri + a * st + k0 + c];
+                            pj[a][c] = A[rj + a * st + k0 + c];
                         }
-                    }
+                    // element (a, b): rows i = b0 + ti + a nt, j = b0 + tj + b nt; it lives at A[max][min] - for a diagonal tile the
+                    // mirrored half (a < b) goes to A[i][j] in the unused upper triangle instead
+                    const bool diag = ti == tj;
+                    int off[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int lo = ri + a * st + (b0 + tj + b * nt);  // A[i][j]
+                            const int up = rj + b * st + (b0 + ti + a * nt);  // A[j][i]
+                            off[a][b] = (a >= b || diag) ? lo : up;             // (ti > tj, a >= b: i > j; a < b: i < j unless... see below)
+                        }
+                    // for ti > tj and a < b the pair is ordered by its rows: i = ti + a nt < j = tj + b nt  <=>  a < b (ti, tj < nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) av[a][b] = A[off[a][b]];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            double sacc = av[a][b];
+#pragma unroll
+                            for (int c = 0; c < NB; ++c) sacc -= pi[a][c] * pj[b][c];
+                            A[off[a][b]] = sacc;
+                        }
+                } else {  // the right-hand-side row: y[j] -= sum_c y[k0 + c] A[j][k0 + c]
+                    const int j = b0 + (t - ntiles);
+                    const double* yk = A + M * lda + k0;
+                    const double* rj = A + j * lda + k0;
+                    double sacc = A[M * lda + j];
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) sacc -= yk[c] * rj[c];
+                    A[M * lda + j] = sacc;
+                }
             }
         }
+        tm.mark(5);
         tm.sync();
+        tm.mark(6);
     }
     return true;
 }
 
-// x = L^-T y by panels from the last one: y = row m of A (from ctl_cholesky), x -> xs[0 .. m).  Per panel every thread solves the
-// small triangular system redundantly; the threads owning an earlier row subtract the panel's contribution from it.
+// x = L^-T y by panels from the last one: y = row M of A (from ctl_cholesky), x -> xs[0 .. M).  Per panel the threads that own
+// an earlier row (or one of the panel's) solve the small triangular system, each for itself, then subtract the panel's
+// contribution from their row.
 template <class TM>
-CBA_HD void ctl_backsolve(TM& tm, double* A, int lda, int m, const double* rdiag, double* xs) {
+CBA_HD void ctl_backsolve(TM& tm, double* A, int lda, int M, const double* Ld, const double* rdiag, double* xs) {
     constexpr int NB = CTL_NB;
-    double* y = A + static_cast<int64_t>(m) * lda;
-    const int last = ((m - 1) / NB) * NB;
-    for (int k0 = last; k0 >= 0; k0 -= NB) {
-        const int nb = m - k0 < NB ? m - k0 : NB;
+    double* y = A + M * lda;
+    for (int k0 = M - NB, p = M / NB - 1; k0 >= 0; k0 -= NB, --p) {
+        const bool mine = tm.tid() < k0 + NB;
         double x[NB];
+        if (mine) {
+            // the panel's triangle, right-hand side and reciprocal pivots first (independent loads), then the dependent chain
+            double Lt[NB][NB], yv[NB], rd[NB];
 #pragma unroll
-        for (int c = NB - 1; c >= 0; --c) {
-            double s = c < nb ? y[k0 + c] : 0.0;
+            for (int c = 0; c < NB; ++c) {
+                yv[c] = y[k0 + c];
+                rd[c] = rdiag[k0 + c];
 #pragma unroll
-            for (int k = c + 1; k < NB; ++k)
-                if (k < nb) s -= A[static_cast<int64_t>(k0 + k) * lda + k0 + c] * x[k];
-            x[c] = c < nb ? s * rdiag[k0 + c] : 0.0;
-        }
-        tm.sync();  // every thread has read y[k0 .. k0 + nb) before anyone overwrites it
-        for (int r = tm.tid(); r < k0 + nb; r += tm.size()) {
-            if (r >= k0) {
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    if (r - k0 == c) xs[r] = x[c];
-                continue;
+                for (int k = c + 1; k < NB; ++k) Lt[k][c] = Ld[(p * NB + k) * NB + c];
             }
-            double s = y[r];
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-                if (c < nb) s -= A[static_cast<int64_t>(k0 + c) * lda + r] * x[c];
-            y[r] = s;
+            for (int c = NB - 1; c >= 0; --c) {
+                double sacc = yv[c];
+#pragma unroll
+                for (int k = c + 1; k < NB; ++k) sacc -= Lt[k][c] * x[k];
+                x[c] = sacc * rd[c];
+            }
         }
+        tm.sync();  // every thread has read y[k0 .. k0 + NB) before anyone overwrites it
+        if (mine)
+            for (int r = tm.tid(); r < k0 + NB; r += tm.size()) {
+                if (r >= k0) {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                        if (r - k0 == c) xs[r] = x[c];
+                    continue;
+                }
+                double sacc = y[r], lv[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) lv[c] = A[(k0 + c) * lda + r];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) sacc -= lv[c] * x[c];
+                y[r] = sacc;
+            }
         tm.sync();
     }
 }
@@ -388,23 +483,41 @@ CBA_HD bool ctl_solve(TM& tm, const CtlView& V, double radius) {
     if (m == 0) { tm.sync(); return true; }
     const double* S = V.pack + V.off_S;
     const double* gs = V.pack + V.off_g;
-    for (int e = tm.tid(); e < (m + 1) * m; e += tm.size()) {
-        const int r = e / m, c = e - r * m;
-        if (r < m) {
-            if (c > r) continue;
-            const int i = V.idx[r], j = V.idx[c];
-            double val = V.Hcc[static_cast<int64_t>(i) * n + j] - S[ctl_sidx(n, i, j)];
-            if (r == c) val += lm_diag(V.Hcc[static_cast<int64_t>(i) * n + i], V.scale2[i], radius);
-            V.A[static_cast<int64_t>(r) * V.lda + c] = val;
-            if (r < CTL_NB) V.Dk[r * CTL_NB + c] = val;
-        } else {
-            const int i = V.idx[c];
-            V.A[static_cast<int64_t>(m) * V.lda + c] = -(V.gc[i] - gs[i]);
+    const int M = (m + CTL_NB - 1) / CTL_NB * CTL_NB;  // padded with identity rows: every panel is full, no guards in the factorisation
+    // rows r of the lower triangle, columns dealt to the threads of a row group: thread t handles rows t / RT, t / RT + RG, ..., of
+    // each the columns t % RT, t % RT + RT, ...  (independent loads, unrolled so that several are in flight)
+    {
+        const int RT = 16, RG = tm.size() >= RT ? tm.size() / RT : 1, cl = tm.size() >= RT ? tm.tid() % RT : 0, rg = tm.size() >= RT ? tm.tid() / RT : 0;
+        const int cstep = tm.size() >= RT ? RT : 1;
+        for (int r = rg; r <= M; r += RG) {
+            double* Arow = V.A + r * V.lda;
+            if (r < m) {
+                const int i = V.idx[r];
+#pragma unroll 4
+                for (int c = cl; c <= r; c += cstep) {
+                    const int j = V.idx[c];
+                    double val = ctl_hcc(V, V.camc, i, j) - S[ctl_sidx(n, i, j)];
+                    if (r == c) val += lm_diag(V.hdiag[i], V.scale2[i], radius);
+                    Arow[c] = val;
+                }
+            } else if (r < M) {
+                for (int c = cl; c <= r; c += cstep) Arow[c] = r == c ? 1.0 : 0.0;
+            } else {
+#pragma unroll 4
+                for (int c = cl; c < M; c += cstep) {
+                    const int i = V.idx[c < m ? c : 0];
+                    const double b = -(V.gc[i] - gs[i]);
+                    Arow[c] = c < m ? b : 0.0;
+                }
+            }
         }
     }
     tm.sync();
-    if (!ctl_cholesky(tm, V.A, V.lda, m, V.Dk, V.rdiag)) return false;
-    ctl_backsolve(tm, V.A, V.lda, m, V.rdiag, V.xs);
+    tm.tick(V, CP_ASSEMBLE);
+    if (!ctl_cholesky(tm, V.A, V.lda, M, V.Ld, V.rdiag, V.okflag)) return false;
+    tm.tick(V, CP_FACTOR);
+    ctl_backsolve(tm, V.A, V.lda, M, V.Ld, V.rdiag, V.xs);
+    tm.tick(V, CP_BACKSOLVE);
     double bad = 0.0;
     for (int r = tm.tid(); r < m; r += tm.size())
         if (!ctl_finite(V.xs[r])) bad = 1.0;
@@ -482,20 +595,29 @@ CBA_HD void ctl_iterate(TM& tm, const CtlView& V) {
     const double* delta = V.x_trial + V.pk_delta;
     double s2, x2;
     ctl_plus(tm, V, V.x_cur, delta, V.x_trial, &s2, &x2);
+    tm.tick(V, CP_PLUS);
     // the shared-shared part of Ceres' model cost change -g^T d - 1/2 d^T H d; the views contribute theirs with the step's exchange
+    // (H_cc is symmetric: thread (group r, column j) adds the rows r, r + G, ... of column j, so neighbours read neighbours)
     double gd = 0.0, dHd = 0.0, dmax = 0.0;
     for (int i = tm.tid(); i < n; i += tm.size()) {
         const double di = delta[i];
         dmax = fmax(dmax, fabs(di));
-        if (di == 0.0) continue;
         gd += V.gc[i] * di;
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += V.Hcc[static_cast<int64_t>(i) * n + j] * delta[j];
-        dHd += di * s;
+    }
+    {   // d^T H_cc d = sum over the cameras' blocks of d_c^T H_c d_c (d in the block's local columns; private pose columns excluded)
+        const int PL = V.PL, PL2 = PL * PL;
+#pragma unroll 4
+        for (int e = tm.tid(); e < V.n_cams * PL2; e += tm.size()) {
+            const int c = e / PL2, rem = e - c * PL2, li = rem / PL, lj = rem - li * PL;
+            const int gi = ctl_shared_col(V, c, li), gj = ctl_shared_col(V, c, lj);
+            if (gi < 0 || gj < 0) continue;
+            dHd += delta[gi] * V.camc[static_cast<int64_t>(c) * V.NACC + hidx_sym(PL, li, lj)] * delta[gj];
+        }
     }
     gd = tm.sum(gd);
     dHd = tm.sum(dHd);
     dmax = tm.max(dmax);
+    tm.tick(V, CP_MODEL);
     if (tm.tid() == 0) {
         V.scal[CS_VALID] = 1.0;
         V.scal[CS_STEP2_SH] = s2; V.scal[CS_XNORM2_SH] = x2; V.scal[CS_GD_SH] = gd; V.scal[CS_DHD_SH] = dHd; V.scal[CS_DMAX] = dmax;
@@ -512,9 +634,12 @@ CBA_HD void ctl_iterate(TM& tm, const CtlView& V) {
 }
 
 // The decision on a trial step whose statistics (the views' share) arrived with the last exchange; cand / step2 / xnorm2 are the
-// totals over the whole state vector.  LMDriver::solve from "model_cost_change" to the radius update.
+// totals over the whole state vector.  LMDriver::solve_host from "model_cost_change" to the radius update.  Returns true when
+// the step was accepted after a SPECULATIVE evaluation: the pack then holds the next system, which the caller adopts (the big
+// pieces - adopt, iterate - appear once in ctl_run: inlined at every use the kernel was 145 KB of code for a 64 KB
+// instruction cache, and ran 10x slower than its dependent chains allow).
 template <class TM>
-CBA_HD void ctl_decide(TM& tm, const CtlView& V, bool speculated, double model_change, double cand, double step2, double xnorm2) {
+CBA_HD bool ctl_decide(TM& tm, const CtlView& V, bool speculated, double model_change, double cand, double step2, double xnorm2) {
     const double eps = V.eps;
     if (tm.tid() == 0) {
         V.scal[CS_INVALID] = 0.0;
@@ -528,12 +653,12 @@ CBA_HD void ctl_decide(TM& tm, const CtlView& V, bool speculated, double model_c
     const double rel = cost_change / model_change;
     tm.sync();
     if (tm.tid() == 0) { V.scal[CS_CAND_COST] = cand; V.scal[CS_REL] = rel; V.scal[CS_MODEL_CHANGE] = model_change; V.scal[CS_SPECULATED] = speculated ? 1.0 : 0.0; }
-    if (step_norm <= eps * (x_norm + eps)) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_PARAMETER); return; }
-    if (fabs(cost_change) <= eps * cost) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_FUNCTION); return; }
+    if (step_norm <= eps * (x_norm + eps)) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_PARAMETER); return false; }
+    if (fabs(cost_change) <= eps * cost) { ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_FUNCTION); return false; }
     if (rel > CTL_MIN_REL_DECREASE) {
-        // accept: the shared blocks here; the host queues the copies of the private poses (and block sums) it is told about
+        // accept: the shared blocks here; the host queues the exchange of the private poses (and block sums) it is told about
         for (int64_t i = tm.tid(); i < V.pk_delta; i += tm.size()) V.x_cur[i] = V.x_trial[i];
-        const double radius_old = V.scal[CS_RADIUS], rspec = V.scal[CS_RADIUS_SPEC];
+        const double radius_old = V.scal[CS_RADIUS];
         const double t3 = 2.0 * rel - 1.0;
         const double radius = fmin(CTL_MAX_RADIUS, radius_old / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3));
         tm.sync();
@@ -545,47 +670,32 @@ CBA_HD void ctl_decide(TM& tm, const CtlView& V, bool speculated, double model_c
             V.scal[CS_DECREASE] = 2.0;
             V.scal[CS_PLAIN_NEXT] = 0.0;
             V.scal[CS_ACCEPT] = speculated ? 2.0 : 1.0;
-        }
-        tm.sync();
-        if (speculated) {
-            ctl_adopt(tm, V, false);  // the exchange that carried the statistics carried the next system
-            if (radius != rspec) {    // gain ratio below 0.937: the elimination was made with another radius
-                if (tm.tid() == 0) {
-                    V.scal[CS_N_MISSES] += 1.0;
-                    V.scal[CS_EXPECT] = CTL_RESOLVED;
-                    V.lmp[0] = radius;
-                    V.lmp[1] = 0.0;
-                }
-            } else {
-                if (tm.tid() == 0) V.scal[CS_N_HITS] += 1.0;
-                tm.sync();
-                ctl_iterate(tm, V);
-            }
-        } else {
-            if (tm.tid() == 0) {
+            if (!speculated) {
                 V.scal[CS_EXPECT] = CTL_NEW;
                 V.lmp[0] = radius;
                 V.lmp[1] = 0.0;
             }
         }
-    } else {
-        if (tm.tid() == 0) {
-            V.scal[CS_N_REJECTED] += 1.0;
-            const double radius = V.scal[CS_RADIUS] / V.scal[CS_DECREASE];
-            V.scal[CS_RADIUS] = radius;
-            V.scal[CS_DECREASE] *= 2.0;
-            V.scal[CS_PLAIN_NEXT] = 1.0;
-            V.scal[CS_EXPECT] = CTL_RESOLVED;
-            V.lmp[0] = radius;
-            V.lmp[1] = 0.0;
-        }
+        tm.sync();
+        return speculated;
     }
+    if (tm.tid() == 0) {
+        V.scal[CS_N_REJECTED] += 1.0;
+        const double radius = V.scal[CS_RADIUS] / V.scal[CS_DECREASE];
+        V.scal[CS_RADIUS] = radius;
+        V.scal[CS_DECREASE] *= 2.0;
+        V.scal[CS_PLAIN_NEXT] = 1.0;
+        V.scal[CS_EXPECT] = CTL_RESOLVED;
+        V.lmp[0] = radius;
+        V.lmp[1] = 0.0;
+    }
+    return false;
 }
 
 // One invocation of the controller, right behind an exchange:
-//   CTL_NEW       the pack holds a new linearisation at the current point (first != 0: the start point)
+//   CTL_NEW       the pack holds a new linearisation at the current point (flag != 0: the start point)
 //   CTL_RESOLVED  the pack holds a re-elimination of the current linearisation [nfail | S | g]
-//   CTL_STEP      the pack holds the statistics of the pending trial step (step_spec != 0: and the system linearised there)
+//   CTL_STEP      the pack holds the statistics of the pending trial step (flag != 0: and the system linearised there)
 //   CTL_LS_DONE   the host ran Ceres' line search on the pending step and left its result in CS_LS_*
 // An invocation whose mode is not the one the controller expects (the host queued it ahead of a decision that turned out
 // otherwise) changes nothing.  Publishes the control record at the end.
@@ -600,26 +710,22 @@ CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
         else V.scal[CS_N_WASTED] += 1.0;
     }
     tm.sync();
+    tm.tick(V, CP_ENTRY);
+    // what this invocation does, in the order: [decide] -> [adopt the pack's system] -> [start the next iteration]
+    enum { AFTER_START = 1, AFTER_NEW = 2, AFTER_STEP = 3 };
+    int adopt = 0;
+    bool iterate = false;
     if (in_turn) {
         if (mode == CTL_NEW) {
-            ctl_adopt(tm, V, flag != 0);
-            if (flag != 0) {
-                if (tm.tid() == 0) V.scal[CS_INITIAL_COST] = V.scal[CS_COST];
-                tm.sync();
-                if (V.scal[CS_GMAX] <= V.eps) ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_GRADIENT);
-                else ctl_iterate(tm, V);
-            } else {
-                ctl_iterate(tm, V);
-            }
+            adopt = flag != 0 ? AFTER_START : AFTER_NEW;
         } else if (mode == CTL_RESOLVED) {
             if (tm.tid() == 0) V.scal[CS_NFAIL] = floor(V.pack[V.off_nfail] + 0.5);
-            tm.sync();
-            ctl_iterate(tm, V);
+            iterate = true;
         } else {  // CTL_STEP, CTL_LS_DONE
             const double* st = V.pack + V.off_stats;
             const bool speculated = mode == CTL_STEP && flag != 0;
             const double gd = st[0] + V.scal[CS_GD_SH], dHd = st[1] + V.scal[CS_DHD_SH];  // PackLayout::GD, DHD
-            double model_change = mode == CTL_STEP ? -gd - 0.5 * dHd : V.scal[CS_MODEL_CHANGE];
+            const double model_change = mode == CTL_STEP ? -gd - 0.5 * dHd : V.scal[CS_MODEL_CHANGE];
             const bool valid = model_change > 0.0 && ctl_finite(model_change);
             double cand = st[4], step2 = st[2] + V.scal[CS_STEP2_SH], xnorm2 = st[3] + V.scal[CS_XNORM2_SH];
             if (mode == CTL_LS_DONE) {
@@ -639,21 +745,45 @@ CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
                     V.scal[CS_SLOPE0] = gd;
                     V.scal[CS_EXPECT] = CTL_LINE_SEARCH;
                 }
-            } else {
-                ctl_decide(tm, V, speculated, model_change, cand, step2, xnorm2);
+            } else if (ctl_decide(tm, V, speculated, model_change, cand, step2, xnorm2)) {
+                adopt = AFTER_STEP;
             }
         }
         tm.sync();
-        if (tm.tid() == 0 && static_cast<int>(V.scal[CS_EXPECT]) == CTL_RESOLVED && V.scal[CS_TERM] < 0.0) {
-            // what follows the re-elimination is known now (its result does not enter the loop-top tests): the host may queue it
-            // behind the re-elimination without waiting for this record's successor
-            int msg;
-            V.scal[CS_WILL_END] = ctl_top_tests(V, &msg) ? 1.0 : 0.0;
-            V.scal[CS_STEP_SPEC] = ctl_next_step_speculative(V) ? 1.0 : 0.0;
+        tm.tick(V, CP_DECIDE);
+    }
+    if (adopt) {
+        ctl_adopt(tm, V, adopt == AFTER_START);
+        if (adopt == AFTER_START) {
+            if (tm.tid() == 0) V.scal[CS_INITIAL_COST] = V.scal[CS_COST];
+            if (V.scal[CS_GMAX] <= V.eps) ctl_end(tm, V, CBA_TERM_CONVERGENCE, CM_GRADIENT);
+            else iterate = true;
+        } else if (adopt == AFTER_NEW) {
+            iterate = true;
+        } else if (V.scal[CS_RADIUS] != V.scal[CS_RADIUS_SPEC]) {  // gain ratio below 0.937: the elimination was made with another radius
+            if (tm.tid() == 0) {
+                V.scal[CS_N_MISSES] += 1.0;
+                V.scal[CS_EXPECT] = CTL_RESOLVED;
+                V.lmp[0] = V.scal[CS_RADIUS];
+                V.lmp[1] = 0.0;
+            }
+        } else {
+            if (tm.tid() == 0) V.scal[CS_N_HITS] += 1.0;
+            iterate = true;
         }
+        tm.sync();
+    }
+    if (iterate) ctl_iterate(tm, V);
+    tm.sync();
+    if (tm.tid() == 0 && static_cast<int>(V.scal[CS_EXPECT]) == CTL_RESOLVED && V.scal[CS_TERM] < 0.0) {
+        // what follows the re-elimination is known now (its result does not enter the loop-top tests): the host may queue it
+        // behind the re-elimination without waiting for this record's successor
+        int msg;
+        V.scal[CS_WILL_END] = ctl_top_tests(V, &msg) ? 1.0 : 0.0;
+        V.scal[CS_STEP_SPEC] = ctl_next_step_speculative(V) ? 1.0 : 0.0;
     }
     tm.sync();
-    if (tm.tid() == 0) tm.publish(V);
+    tm.publish(V);
 }
 
 // the control scalars at the start of a solve

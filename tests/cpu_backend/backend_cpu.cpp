@@ -299,10 +299,12 @@ struct CpuBackend final : Backend {
 
     // ---- the controller form of the iteration: lm_ctl.hpp run by a team of one host thread -----------------------------------
     struct Ctl {
-        std::vector<double> scal, Hcc, gc, scale2, xs, rdiag, Dk, x[3], A, pack, rec;
+        std::vector<double> scal, camc, hdiag, gc, scale2, xs, rdiag, Ld, x[3], A, pack, rec;
+        std::vector<int> colcam, collc;
         std::vector<int8_t> eff, active, cam_var;
         std::vector<int> idx;
         double lmp[2] = {1e4, 1.0};
+        int okflag = 1;
         CtlView V;
         bool constrained = false;
     } ctl;
@@ -331,11 +333,12 @@ struct CpuBackend final : Backend {
         ctl.constrained = cs.constrained;
         ctl.scal.assign(CS_COUNT, 0.0); ctl.rec.assign(CS_COUNT, 0.0);
         ctl_reset(ctl.scal.data());
-        ctl.Hcc.assign(static_cast<size_t>(n) * n, 0.0); ctl.gc.assign(n, 0.0); ctl.scale2.assign(n, 1.0); ctl.xs.assign(n, 0.0);
-        ctl.rdiag.assign(n, 0.0); ctl.Dk.assign(CTL_NB * CTL_NB, 0.0);
+        const int M8 = ctl_padded(n);
+        ctl.camc.assign(static_cast<size_t>(s.n_cams) * s.NACC, 0.0); ctl.hdiag.assign(n, 0.0); ctl.gc.assign(n, 0.0); ctl.scale2.assign(n, 1.0); ctl.xs.assign(M8, 0.0);
+        ctl.rdiag.assign(M8, 0.0); ctl.Ld.assign(static_cast<size_t>(M8) * CTL_NB, 0.0);
         for (int k = 0; k < 3; ++k) ctl.x[k].assign(static_cast<size_t>(V.pk_delta) + n, 0.0);
-        V.lda = n | 1;
-        ctl.A.assign(static_cast<size_t>(n + 1) * V.lda, 0.0);
+        V.lda = ctl_lda(n);
+        ctl.A.assign(static_cast<size_t>(M8 + 1) * V.lda, 0.0);
         ctl.pack.assign(static_cast<size_t>(L.size), 0.0);
         ctl.eff.assign(n, 0); ctl.idx.assign(n, 0);
         ctl.active.assign(cs.active->begin(), cs.active->end());
@@ -346,9 +349,12 @@ struct CpuBackend final : Backend {
         ctl.x[1] = ctl.x[0];
         ctl.lmp[0] = 1e4; ctl.lmp[1] = 1.0;
         V.x_cur = ctl.x[0].data(); V.x_trial = ctl.x[1].data(); V.x_tmp = ctl.x[2].data();
-        V.scal = ctl.scal.data(); V.pack = ctl.pack.data(); V.Hcc = ctl.Hcc.data(); V.gc = ctl.gc.data(); V.scale2 = ctl.scale2.data();
+        ctl.colcam.assign(n, 0); ctl.collc.assign(n, 0);
+        for (int i = 0; i < n; ++i) ctl_decode(V, i, &ctl.colcam[i], &ctl.collc[i]);
+        V.colcam = ctl.colcam.data(); V.collc = ctl.collc.data();
+        V.scal = ctl.scal.data(); V.pack = ctl.pack.data(); V.camc = ctl.camc.data(); V.hdiag = ctl.hdiag.data(); V.gc = ctl.gc.data(); V.scale2 = ctl.scale2.data();
         V.eff = ctl.eff.data(); V.active = ctl.active.data(); V.cam_var = ctl.cam_var.data(); V.idx = ctl.idx.data();
-        V.A = ctl.A.data(); V.rdiag = ctl.rdiag.data(); V.xs = ctl.xs.data(); V.Dk = ctl.Dk.data(); V.lmp = ctl.lmp; V.rec = ctl.rec.data();
+        V.A = ctl.A.data(); V.rdiag = ctl.rdiag.data(); V.xs = ctl.xs.data(); V.Ld = ctl.Ld.data(); V.lmp = ctl.lmp; V.rec = ctl.rec.data(); V.okflag = &ctl.okflag;
         return true;
     }
     void ctl_new(double hub, bool first, const PackLayout& L, const AllReduce& ar, int rank) override {
