@@ -149,8 +149,9 @@ __global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_row_sum(int64_t n_rows,
 // single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4); if aux: out[w] = max_i aux[i] and out[w + 1] = #{i : aux[i] < 0}
 // (k_schur_view marks a view whose damped H_pp is not positive definite with -1).  `out` may be page-locked host memory.
 __global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
-                                                    double* __restrict__ out) {
+                                                    double* __restrict__ out, const double* __restrict__ gate = nullptr) {
     __shared__ double sh[6][256];
+    if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
     double acc[4] = {0, 0, 0, 0}, mx = 0.0, bad = 0.0;
     for (int i = static_cast<int>(threadIdx.x); i < n; i += 256) {
         for (int c = 0; c < w; ++c) acc[c] += in[static_cast<int64_t>(i) * w + c];
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256) void k_backsub_wave(SchurDims d, int n_views, 
                                                       const double* __restrict__ blk_Z, const double* __restrict__ delta_sh,
                                                       const int32_t* __restrict__ fixed, const double* __restrict__ L, const double* __restrict__ y,
                                                       const double* __restrict__ D, const double* __restrict__ gp, const double* __restrict__ x,
-                                                      double* __restrict__ delta_p, double* __restrict__ xt, double* __restrict__ stats) {
+                                                      double* __restrict__ delta_p, double* __restrict__ xt, double* __restrict__ stats,
+                                                      const double* __restrict__ gate = nullptr) {
+    if (gate && *gate == 0.0) return;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
@@ -416,7 +419,8 @@ __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ 
                           const double* __restrict__ delta_sh, const int32_t* __restrict__ fixed, const double* __restrict__ L,
                           const double* __restrict__ y, const double* __restrict__ D, const double* __restrict__ gp,
                           const double* __restrict__ x, double* __restrict__ delta_p, double* __restrict__ xt,
-                          double* __restrict__ stats /*[n_views][4]*/) {
+                          double* __restrict__ stats /*[n_views][4]*/, const double* __restrict__ gate = nullptr) {
+    if (gate && *gate == 0.0) return;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
@@ -588,12 +592,18 @@ struct HipBackend final : Backend {
     }
     // which: parameter copy to linearise at; cam_out [n_cams][NACC] and cost_out {cost, sum s} may be device or page-locked host memory
     void enqueue_normal_eq(double huber, int which = 0, double* cam_out = nullptr, double* cost_out = nullptr) {
+        enqueue_normal_eq_head(which);
+        enqueue_normal_eq_tail(huber, cam_out, cost_out);
+    }
+    void enqueue_normal_eq_head(int which) {  // block constants at copy `which`, Mode B: the per-block [H | g | s]
+        launch_block_consts(e, which);
+        launch_normal_eq(e);
+    }
+    void enqueue_normal_eq_tail(double huber, double* cam_out = nullptr, double* cost_out = nullptr) {  // weights, cost, per-camera sums
         const Structure& s = st.s;
         const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
         if (!cam_out) cam_out = st.pin_ne.p;
         if (!cost_out) cost_out = st.pin_ne.p + nca;
-        launch_block_consts(e, which);
-        launch_normal_eq(e);
         const bool fused_cost = s.n_blocks <= 4096;
         if (fused_cost)
             hipLaunchKernelGGL(k_weights_cost, dim3(1), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL, e.blk_acc.p, huber,
@@ -818,7 +828,7 @@ struct HipBackend final : Backend {
         if (q2) {  // statistics of the step from the CURRENT factors, trial poses into copy 1
             hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)), st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
-                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p, static_cast<const double*>(nullptr));
             hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
                                static_cast<const double*>(nullptr), st.stat_dev.p);
         } else {
@@ -942,6 +952,10 @@ struct HipBackend final : Backend {
     void run_ctl(int mode, int flag) {
         launch_lm_ctl(st.ctl_view, mode, flag, e.stream);
         ++ctl_invocations;
+        // what ctl_wait() sleeps on when polling the record has taken too long: an event right behind THIS launch (the stream may
+        // already hold the gated head of the next step behind it, which must not be waited for)
+        if (!st.ctl_done) CBA_HIP(hipEventCreateWithFlags(&st.ctl_done, hipEventDisableTiming));
+        CBA_HIP(hipEventRecord(st.ctl_done, e.stream));
     }
     bool ctl_begin(const CtlSetup& cs, const PackLayout& L) override {
         if (!st.lm_ctl_mode) return false;
@@ -1001,46 +1015,96 @@ struct HipBackend final : Backend {
         hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)),
                            st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p, st.link_blk.p, e.d_blk_cam.p,
                            e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p, e.view_D.p, e.view_gp.p, e.view[0].p,
-                           st.view_delta.p, e.view[1].p, st.view_stats.p);
+                           st.view_delta.p, e.view[1].p, st.view_stats.p, e.gate);
         hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p, static_cast<const double*>(nullptr),
-                           st.stat_dev.p);
+                           st.stat_dev.p, e.gate);
+    }
+    // The head of a speculative step: back-substitution, then block constants and Mode B at the trial point into the SECOND set of
+    // block sums (the current set stays valid for a rejected step).  Nothing in it needs the host.
+    void step_head_speculative() {
+        const Structure& s = st.s;
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        if (q2) enqueue_backsub();
+        else CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        if (q1) {
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            try {
+                enqueue_normal_eq_head(1);
+            } catch (...) {
+                std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+                throw;
+            }
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+        }
+    }
+    void step_tail_speculative(double huber, const PackLayout& L, const AllReduce& ar) {
+        const Structure& s = st.s;
+        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+        std::swap(e.blk_w.p, e.blk_w_alt.p);
+        try {
+            if (q1) enqueue_normal_eq_tail(huber, pack_target() + L.cam, st.stat_dev.p + 4);
+            if (q2) enqueue_schur(ctl_constrained, 1, st.sys_tiles.p);  // with the radius the controller predicted
+        } catch (...) {
+            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
+            throw;
+        }
+        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+        std::swap(e.blk_w.p, e.blk_w_alt.p);
+        enqueue_pack(L, q1, q2, 1);
+        exchange(0, L.size, ar, nullptr, true);
+        run_ctl(CTL_STEP, 1);
+        e.active = 1;
     }
     void ctl_step(double huber, bool speculative, const PackLayout& L, const AllReduce& ar, int rank) override {
         (void)rank;
         const Structure& s = st.s;
         const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
         // the shared trial blocks and the shared step are where the controller left them (copy 1)
+        if (speculative) {
+            step_head_speculative();
+            step_tail_speculative(huber, L, ar);
+            return;
+        }
         if (q2) enqueue_backsub();
         else CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
-        if (speculative) {
-            // linearise at the trial point into the second set of block sums / weights; the current set stays valid for a rejected step
-            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-            std::swap(e.blk_w.p, e.blk_w_alt.p);
-            try {
-                if (q1) enqueue_normal_eq(huber, 1, pack_target() + L.cam, st.stat_dev.p + 4);
-                if (q2) enqueue_schur(ctl_constrained, 1, st.sys_tiles.p);  // with the radius the controller predicted
-            } catch (...) {
-                std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-                std::swap(e.blk_w.p, e.blk_w_alt.p);
-                throw;
-            }
-            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-            std::swap(e.blk_w.p, e.blk_w_alt.p);
-            enqueue_pack(L, q1, q2, 1);
-            exchange(0, L.size, ar, nullptr, true);
+        if (q1) {  // the cost alone (Mode R); the block sums / weights of the current point stay
+            launch_block_consts(e, 1);
+            launch_resid(e);
+            launch_cost(e, huber, st.stat_dev.p + 4);
         } else {
-            if (q1) {  // the cost alone (Mode R); the block sums / weights of the current point stay
-                launch_block_consts(e, 1);
-                launch_resid(e);
-                launch_cost(e, huber, st.stat_dev.p + 4);
-            } else {
-                CBA_HIP(hipMemsetAsync(st.stat_dev.p + 4, 0, sizeof(double), e.stream));
-            }
-            enqueue_pack(L, false, false, 1, 1);
-            exchange(L.stats, 6, ar, nullptr, true);
+            CBA_HIP(hipMemsetAsync(st.stat_dev.p + 4, 0, sizeof(double), e.stream));
         }
-        run_ctl(CTL_STEP, speculative ? 1 : 0);
+        enqueue_pack(L, false, false, 1, 1);
+        exchange(L.stats, 6, ar, nullptr, true);
+        run_ctl(CTL_STEP, 0);
         e.active = 1;
+    }
+    // Queue the head of the NEXT speculative step behind the controller invocation that was just queued, before its decision is
+    // known: every launch of the head checks the controller's CS_GO flag on the device and does nothing unless the controller
+    // accepted the step it decided on with the predicted radius and asks for another speculative step - the usual case, in which
+    // the chip goes from the controller straight into the next step (the host's read of the record and its ~15 launches of 3-5 us
+    // are off the critical path).  The head assumes the accept has happened: the buffer exchange is made here and undone by
+    // ctl_prelaunch_cancel() if the record says otherwise.
+    bool ctl_prelaunch() override {
+        if (!st.ctl_prelaunch || e.scalar || !e.modeb_shared || (e.chain != CBA_CHAIN_INTRINSIC && !e.modeb_moments)) return false;
+        ctl_accept(true);
+        e.gate = st.ctl_view.scal + CS_GO;
+        try {
+            step_head_speculative();
+        } catch (...) {
+            e.gate = nullptr;
+            ctl_accept(true);
+            throw;
+        }
+        e.gate = nullptr;
+        return true;
+    }
+    void ctl_prelaunch_cancel() override { ctl_accept(true); }  // (the gated launches did nothing)
+    void ctl_step_tail(double huber, const PackLayout& L, const AllReduce& ar, int rank) override {
+        (void)rank;
+        step_tail_speculative(huber, L, ar);
     }
     // trial -> current without a copy: the two sets of private poses (and, after a speculative step, of block sums and weights)
     // trade places.  A stage graph captured with the old pointers would be stale: the captured stages belong to the host-side
@@ -1068,7 +1132,7 @@ struct HipBackend final : Backend {
             }
         }
         if (*seq < want) {
-            CBA_HIP(hipStreamSynchronize(e.stream));
+            CBA_HIP(hipEventSynchronize(st.ctl_done));
             if (*seq < want) throw HipError("LM controller: the control record did not arrive");
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1101,7 +1165,7 @@ struct HipBackend final : Backend {
             if (s.n_views > 0) {
                 hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)), st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
                                    st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
-                                   e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p);
+                                   e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p, static_cast<const double*>(nullptr));
                 hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
                                    static_cast<const double*>(nullptr), st.pin_tr.p + 8);
             }
@@ -1220,6 +1284,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->res_out.alloc(32);
     if (const char* env = std::getenv("CBA_LM_CTL")) st->lm_ctl_mode = std::atoi(env) != 0;
     if (const char* env = std::getenv("CBA_LM_CTL_POLL_US")) st->ctl_poll_us = std::atoi(env);
+    if (const char* env = std::getenv("CBA_LM_PRELAUNCH")) st->ctl_prelaunch = std::atoi(env);
     warm_lm_ctl();
     if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_RESIDENT_MAX_OBS")) st->resident_max_obs = std::atoll(env);

@@ -195,6 +195,8 @@ struct Engine {
     int eval_ablate = 0;  // timing-only ablation of k_eval (CBA_EVAL_ABLATE; outputs are wrong when non-zero)
     int eval_variant = 1;  // k_eval variant: bit 0 = non-temporal stores, bits 1.. = log2(tiles per wave)
     int active = 0;  // parameter copy (0 current / 1 trial) the constants bc, sd were last built from
+    const double* gate = nullptr;  // device flag the launches of block constants / Mode B check (0: do nothing); set by the LM driver
+                                   // while it queues the head of a step ahead of the controller's decision, nullptr otherwise
     DevBuf<int32_t> d_blk_cam, d_blk_view;
     DevBuf<Tile> tilesA, tilesB;
     DevBuf<int64_t> d_blk_tile_off;

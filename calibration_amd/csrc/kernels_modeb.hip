@@ -130,12 +130,13 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 
 // one workgroup of FORM::NPARTS wavefronts per tile
 template <class FORM, int NBUF, typename T, int ABL = 0, bool ONE = false>
-__global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
+__global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const double* __restrict__ gate, const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
                                                                   const T* __restrict__ Y, const T* __restrict__ u, const T* __restrict__ v,
                                                                   int PI, double* __restrict__ partial) {
     __shared__ v2f64 sh[NBUF * FORM::NPARTS][ShareDims<FORM>::NR2][64];
+    if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
     const int64_t w = blockIdx.x;
     if (w >= n_tiles) return;
     const Tile t = tiles[w];
@@ -159,9 +160,9 @@ static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, cons
     static const bool one_ok = !(std::getenv("CBA_MODEB_ONEGROUP") && std::atoi(std::getenv("CBA_MODEB_ONEGROUP")) == 0);
     if (NBUF == 1 && one_ok && e.max_tileB <= 64 * FORM::NPARTS)  // every tile is one group: the single-group kernel
         hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream,
-                           e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+                           e.gate, e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
     else
-        hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.tilesB.p,
+        hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.gate, e.tilesB.p,
                            e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
 }
 
@@ -204,7 +205,7 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
             else if (variant >= 32 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
                 using F = MomentForm<CAM_PINHOLE_BC, 3, double>;
                 const dim3 g(static_cast<unsigned>(e.n_tilesB)), b(64 * 3);
-#define CBA_ABL(A) hipLaunchKernelGGL((k_ne_shared<F, 1, double, A>), g, b, 0, e.stream, e.tilesB.p, e.n_tilesB, e.bc.p, e.intr[e.active].p, e.sd.p, \
+#define CBA_ABL(A) hipLaunchKernelGGL((k_ne_shared<F, 1, double, A>), g, b, 0, e.stream, e.gate, e.tilesB.p, e.n_tilesB, e.bc.p, e.intr[e.active].p, e.sd.p, \
                                       e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.PI, rows)
                 if (variant == 33) CBA_ABL(1); else if (variant == 34) CBA_ABL(2); else CBA_ABL(3);
 #undef CBA_ABL

@@ -29,10 +29,14 @@ __device__ __forceinline__ int64_t wave_index() {
 }
 
 template <int CHAIN>
-__global__ void k_block_consts(int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
+// gate (every kernel that takes one): nullptr, or a flag in device memory; when it reads 0 the launch does nothing.  The LM driver
+// queues the head of the NEXT step behind the controller before it knows the controller's decision (lm_core.hpp solve_ctl): the
+// controller sets the flag when the step it decided on is the one that was queued.
+__global__ void k_block_consts(const double* __restrict__ gate, int n_blocks, const int32_t* __restrict__ blk_cam, const int32_t* __restrict__ blk_view,
                                const double* __restrict__ cam, const double* __restrict__ view,
                                const double* __restrict__ target, const double* __restrict__ aux, double* __restrict__ bc,
                                float* __restrict__ bcf) {
+    if (gate && *gate == 0.0) return;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const double *pA, *pB = nullptr, *ax = nullptr;
@@ -53,8 +57,9 @@ __global__ void k_block_consts(int n_blocks, const int32_t* __restrict__ blk_cam
         for (int i = 0; i < BC_SIZE; ++i) bcf[static_cast<int64_t>(b) * BC_SIZE + i] = static_cast<float>(out[i]);
 }
 
-__global__ void k_scheimpflug_consts(int n_cams, const double* __restrict__ intr, double* __restrict__ sd,
+__global__ void k_scheimpflug_consts(const double* __restrict__ gate, int n_cams, const double* __restrict__ intr, double* __restrict__ sd,
                                      float* __restrict__ sdf) {
+    if (gate && *gate == 0.0) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cams) return;
     double out[SD_SIZE];
@@ -194,8 +199,9 @@ __global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, i
 }
 
 // out[b][e] = sum over the block's tiles (in tile order) of partial[t][e]
-__global__ void k_tile_sum(int n_blocks, int width, const int64_t* __restrict__ blk_tile_off,
+__global__ void k_tile_sum(const double* __restrict__ gate, int n_blocks, int width, const int64_t* __restrict__ blk_tile_off,
                            const double* __restrict__ partial, double* __restrict__ out) {
+    if (gate && *gate == 0.0) return;
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= static_cast<int64_t>(n_blocks) * width) return;
     const int b = static_cast<int>(idx / width);
@@ -343,8 +349,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
 
 // blk_acc[b] = packed [H | g | s] of block b from its moment row; one wavefront per block, G and T = Qh Gh in LDS
 template <int CHAIN, int PI>
-__global__ __launch_bounds__(64) void k_mom_expand(int n_blocks, const double* __restrict__ bc, const double* __restrict__ blk_mom,
+__global__ __launch_bounds__(64) void k_mom_expand(const double* __restrict__ gate, int n_blocks, const double* __restrict__ bc, const double* __restrict__ blk_mom,
                                                    double* __restrict__ blk_acc) {
+    if (gate && *gate == 0.0) return;
     constexpr int PL = 12 + PI, NH = PL * (PL + 1) / 2, NACC = NH + PL + 1, NMOM = MomLayout<PI>::N;
     static constexpr UpperIndex<PL> UI{};
     __shared__ double G[3][36];
@@ -408,19 +415,19 @@ void launch_block_consts(Engine& e, int which) {
     float* bcf = e.scalar ? e.bcf.p : nullptr;
     switch (e.chain) {
         case CH_INTRINSIC:
-            hipLaunchKernelGGL(k_block_consts<CH_INTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+            hipLaunchKernelGGL(k_block_consts<CH_INTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.gate, e.n_blocks, e.d_blk_cam.p,
                                e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
             break;
         case CH_EXTRINSIC:
-            hipLaunchKernelGGL(k_block_consts<CH_EXTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+            hipLaunchKernelGGL(k_block_consts<CH_EXTRINSIC>, dim3(g), dim3(128), 0, e.stream, e.gate, e.n_blocks, e.d_blk_cam.p,
                                e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
             break;
         default:
-            hipLaunchKernelGGL(k_block_consts<CH_BUNDLE>, dim3(g), dim3(128), 0, e.stream, e.n_blocks, e.d_blk_cam.p,
+            hipLaunchKernelGGL(k_block_consts<CH_BUNDLE>, dim3(g), dim3(128), 0, e.stream, e.gate, e.n_blocks, e.d_blk_cam.p,
                                e.d_blk_view.p, cam, view, target, e.aux.p, e.bc.p, bcf);
     }
     if (e.model == CAM_SCHEIMPFLUG)
-        hipLaunchKernelGGL(k_scheimpflug_consts, dim3(blocks_for(e.n_cams, 64)), dim3(64), 0, e.stream, e.n_cams,
+        hipLaunchKernelGGL(k_scheimpflug_consts, dim3(blocks_for(e.n_cams, 64)), dim3(64), 0, e.stream, e.gate, e.n_cams,
                            e.intr[which].p, e.sd.p, e.scalar ? e.sdf.p : nullptr);
     if (e.scalar)
         hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(static_cast<int64_t>(e.n_cams) * e.PI, 64)), dim3(64), 0, e.stream,
@@ -494,7 +501,7 @@ void launch_resid(Engine& e) {
 #undef RESID_F64
 #undef RESID_F32
     if (!one_tile_per_block(e))
-        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(e.n_blocks, 256)), dim3(256), 0, e.stream, e.n_blocks, 1,
+        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(e.n_blocks, 256)), dim3(256), 0, e.stream, e.gate, e.n_blocks, 1,
                            e.d_blk_tile_off.p, e.partial.p, e.blk_s.p);
     CBA_HIP(hipGetLastError());
 }
@@ -575,9 +582,9 @@ static void launch_mom(Engine& e, unsigned g) {
     }
     const int64_t tot = static_cast<int64_t>(e.n_blocks) * NMOM;
     if (!one_tile_per_block(e))
-        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.n_blocks, NMOM, e.d_blk_tile_off.p, e.partial.p,
+        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.gate, e.n_blocks, NMOM, e.d_blk_tile_off.p, e.partial.p,
                            e.blk_mom.p);
-    hipLaunchKernelGGL((k_mom_expand<C, PI>), dim3(e.n_blocks), dim3(64), 0, e.stream, e.n_blocks, e.bc.p, e.blk_mom.p, e.blk_acc.p);
+    hipLaunchKernelGGL((k_mom_expand<C, PI>), dim3(e.n_blocks), dim3(64), 0, e.stream, e.gate, e.n_blocks, e.bc.p, e.blk_mom.p, e.blk_acc.p);
 }
 
 void launch_normal_eq(Engine& e) {
@@ -594,7 +601,7 @@ void launch_normal_eq(Engine& e) {
 #undef CALL
     const int64_t tot = static_cast<int64_t>(e.n_blocks) * e.NACC;
     if (!one_tile_per_block(e))
-        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.n_blocks, e.NACC,
+        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.gate, e.n_blocks, e.NACC,
                            e.d_blk_tile_off.p, e.partial.p, e.blk_acc.p);
     CBA_HIP(hipGetLastError());
 }

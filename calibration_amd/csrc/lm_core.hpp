@@ -176,6 +176,13 @@ struct Backend {
     virtual void ctl_step(double huber, bool speculative, const PackLayout& L, const AllReduce& ar, int rank) { (void)huber; (void)speculative; (void)L; (void)ar; (void)rank; }
     // the last trial was accepted: private poses (and, after a speculative step, block sums and weights) trial -> current
     virtual void ctl_accept(bool blocks) { (void)blocks; }
+    // Queue the head of the next speculative step (back-substitution, block constants, Mode B at the trial point) right behind the
+    // controller invocation queued last, BEFORE its decision is known; the launches do nothing unless the controller's CS_GO flag
+    // says that this is the step it asks for.  false: not supported.  If the record then confirms CS_GO the driver calls
+    // ctl_step_tail() (the rest of the step), otherwise ctl_prelaunch_cancel().
+    virtual bool ctl_prelaunch() { return false; }
+    virtual void ctl_prelaunch_cancel() {}
+    virtual void ctl_step_tail(double huber, const PackLayout& L, const AllReduce& ar, int rank) { (void)huber; (void)L; (void)ar; (void)rank; }
     virtual const double* ctl_wait() { return nullptr; }
     // current shared blocks and the pending shared step, for the host side of a line search / the end of the solve
     virtual void ctl_fetch(double* intr, double* cam, double* target, double* delta) { (void)intr; (void)cam; (void)target; (void)delta; }
@@ -209,6 +216,7 @@ class LMDriver {
         if (const char* env = std::getenv("CBA_LM_LINE_SEARCH")) line_search_ = std::atoi(env) != 0;
         if (const char* env = std::getenv("CBA_LM_CTL")) use_ctl_ = std::atoi(env) != 0;
         if (const char* env = std::getenv("CBA_LM_PIPELINE")) pipeline_ = std::atoi(env) != 0;
+        if (const char* env = std::getenv("CBA_LM_PRELAUNCH")) prelaunch_ = std::atoi(env) != 0;
     }
     LMDriver(const LMDriver&) = delete;  // ar_ captures `this`
     LMDriver& operator=(const LMDriver&) = delete;
@@ -303,6 +311,7 @@ class LMDriver {
         be_.ctl_new(huber, true, L_, ar_, rank_);
         wait();
         double last_printed = 0;
+        bool pre = false;  // the head of a speculative step is queued behind the controller invocation being waited for
         while (rec[CS_TERM] < 0.0) {
             const auto q0 = now();
             const int expect = static_cast<int>(rec[CS_EXPECT]);
@@ -312,24 +321,37 @@ class LMDriver {
                             rec[CS_P_COST], rec[CS_CAND_COST], rec[CS_REL], rec[CS_P_RADIUS], rec[CS_P_GMAX],
                             rec[CS_SPECULATED] != 0.0 ? " (speculative)" : "");
             }
-            if (rec[CS_ACCEPT] != 0.0) be_.ctl_accept(rec[CS_ACCEPT] == 2.0);
-            if (expect == CTL_STEP) {
-                be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
-            } else if (expect == CTL_RESOLVED) {
-                be_.ctl_resolve(L_, ar_, rank_);
-                // what follows the re-elimination does not depend on its result (unless the reduced system turns out unsolvable,
-                // in which case the controller ignores the step): queue it behind, one wait for both
-                if (pipeline_ && rec[CS_WILL_END] == 0.0) be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
-            } else if (expect == CTL_NEW) {
-                be_.ctl_new(huber, false, L_, ar_, rank_);
-            } else if (expect == CTL_LINE_SEARCH) {
-                ctl_line_search(huber, rec);
+            bool queued_spec = false;  // the last thing queued in this pass is a speculative step
+            if (pre && rec[CS_GO] != 0.0) {  // as predicted: the step's head is already running; queue the rest
+                be_.ctl_step_tail(huber, L_, ar_, rank_);
+                queued_spec = true;
             } else {
-                throw std::runtime_error("LM controller: unexpected request");
+                if (pre) be_.ctl_prelaunch_cancel();
+                if (rec[CS_ACCEPT] != 0.0) be_.ctl_accept(rec[CS_ACCEPT] == 2.0);
+                if (expect == CTL_STEP) {
+                    be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
+                    queued_spec = rec[CS_STEP_SPEC] != 0.0;
+                } else if (expect == CTL_RESOLVED) {
+                    be_.ctl_resolve(L_, ar_, rank_);
+                    // what follows the re-elimination does not depend on its result (unless the reduced system turns out unsolvable,
+                    // in which case the controller ignores the step): queue it behind, one wait for both
+                    if (pipeline_ && rec[CS_WILL_END] == 0.0) {
+                        be_.ctl_step(huber, rec[CS_STEP_SPEC] != 0.0, L_, ar_, rank_);
+                        queued_spec = rec[CS_STEP_SPEC] != 0.0;
+                    }
+                } else if (expect == CTL_NEW) {
+                    be_.ctl_new(huber, false, L_, ar_, rank_);
+                } else if (expect == CTL_LINE_SEARCH) {
+                    ctl_line_search(huber, rec);
+                } else {
+                    throw std::runtime_error("LM controller: unexpected request");
+                }
             }
+            pre = prelaunch_ && queued_spec && be_.ctl_prelaunch();
             t_queue += us(q0, now());
             wait();
         }
+        if (pre) be_.ctl_prelaunch_cancel();
         // the accepted point: shared blocks from the controller, private poses from the backend
         {
             std::vector<double> d(std::max(1, s_.nsh));
@@ -984,6 +1006,7 @@ class LMDriver {
     bool line_search_ = true;
     bool use_ctl_ = true;    // the controller form of the iteration when the backend has one (CBA_LM_CTL=0: host-side form)
     bool pipeline_ = true;   // queue a re-elimination and the step behind it together (CBA_LM_PIPELINE=0: one wait each)
+    bool prelaunch_ = true;  // queue the head of the next speculative step before the controller's decision is known (CBA_LM_PRELAUNCH=0)
     ExchangeStats xs_;
     std::vector<char> active_, eff_;
     std::vector<char> cam_var_;

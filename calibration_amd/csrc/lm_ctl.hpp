@@ -37,6 +37,8 @@ enum CtlSlot : int {
     CS_STEP_SPEC,      // the next trial step is evaluated speculatively (linearised at the trial point) / the cheap way (cost only)
     CS_ACCEPT,         // 0 nothing; 1 the last trial was accepted after a plain evaluation (private poses trial -> current);
                        // 2 accepted after a speculative one (poses + block sums + weights)
+    CS_GO,             // 1: this invocation accepted a speculative step with the predicted radius and asks for another speculative
+                       // step - the launches the driver queued ahead of this decision (gated on this flag) are the right ones
     CS_WILL_END,       // with CS_EXPECT = RESOLVED: the loop-top tests after the re-elimination will end the solve (no step follows)
     CS_RADIUS, CS_DECREASE, CS_RADIUS_SPEC, CS_COST, CS_GMAX, CS_GMAX_PRIV, CS_INITIAL_COST, CS_REL_LAST, CS_REL_PREV,
     CS_ITER, CS_SUCCESSFUL, CS_INVALID, CS_VALID, CS_PLAIN_NEXT, CS_NFAIL, CS_M,
@@ -706,6 +708,7 @@ CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
     tm.sync();
     if (tm.tid() == 0) {
         V.scal[CS_SEQ] += 1.0;
+        V.scal[CS_GO] = 0.0;
         if (in_turn) { V.scal[CS_ACCEPT] = 0.0; V.scal[CS_WILL_END] = 0.0; }
         else V.scal[CS_N_WASTED] += 1.0;
     }
@@ -782,6 +785,9 @@ CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
         V.scal[CS_WILL_END] = ctl_top_tests(V, &msg) ? 1.0 : 0.0;
         V.scal[CS_STEP_SPEC] = ctl_next_step_speculative(V) ? 1.0 : 0.0;
     }
+    if (tm.tid() == 0)
+        V.scal[CS_GO] = (in_turn && V.scal[CS_TERM] < 0.0 && static_cast<int>(V.scal[CS_EXPECT]) == CTL_STEP && V.scal[CS_STEP_SPEC] != 0.0 &&
+                         V.scal[CS_ACCEPT] == 2.0) ? 1.0 : 0.0;
     tm.sync();
     tm.publish(V);
 }

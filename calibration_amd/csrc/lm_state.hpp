@@ -28,8 +28,12 @@ struct HipLMState {
     // the ONE wait of an LM step: hipStreamSynchronize sleeps on an interrupt (20-50 us to wake up on ROCm 7.2, more than the
     // whole host side of a step); polling an event recorded behind the stage returns within a few us (CBA_SYNC_SPIN=0: sleep)
     hipEvent_t step_done = nullptr;
+    hipEvent_t ctl_done = nullptr;  // recorded behind every controller launch (ctl_wait)
     int sync_spin = 1;
-    ~HipLMState() { if (step_done) (void)hipEventDestroy(step_done); }
+    ~HipLMState() {
+        if (step_done) (void)hipEventDestroy(step_done);
+        if (ctl_done) (void)hipEventDestroy(ctl_done);
+    }
     int64_t xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ExchangeStats of the last solve (cba_reproj_solve_stats)
     // The three launch sequences of an LM iteration are HIP graphs (captured from the stream on first use): a stage is one
     // hipGraphLaunch instead of 7-15 kernel launches and copies — the iteration is host-launch bound for small and mid-size
@@ -68,6 +72,7 @@ struct HipLMState {
     PinnedBuf<double> ctl_rec;  // [control record CS_COUNT | staging of the scalars CS_COUNT | staging of the start point pk_size]
     CtlView ctl_view{};
     int ctl_n = -1;             // reduced size the buffers above were laid out for
+    int ctl_prelaunch = 1;      // queue the head of the next step behind the controller before its decision is known (CBA_LM_PRELAUNCH)
     int ctl_poll_us = 400;      // how long ctl_wait polls the record before it sleeps on the stream
     int lm_ctl_mode = 1;        // 1 = the controller form of the host-driven iteration (default), 0 = the host-side form (CBA_LM_CTL)
 };
