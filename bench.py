@@ -14,6 +14,7 @@ north-star's obs-sharded strong-scaling case; wall clock, collective count and b
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
 """
 import argparse
+import copy
 import ctypes as C
 import json
 import os
@@ -35,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=1000)
     ap.add_argument("--grid", type=int, default=100, help="points per view = grid^2")
+    ap.add_argument("--pitch", type=float, default=0.002, help="target pitch in metres (SURVEY.md section 8d: 0.002 m for the 100 x 100 board of C2 / C5)")
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lm-timeout", type=float, default=240.0, help="watchdog for the LM section, seconds")
@@ -73,7 +75,7 @@ def main():
 
     # ---- synthetic scene: this rank's shard of the (world * views)-view problem ----------------------
     t_gen = time.time()
-    scene = synth.scene_intrinsics(args.views, rows=args.grid, cols=args.grid, spacing=0.8 / args.grid, seed=7 + rank,
+    scene = synth.scene_intrinsics(args.views, rows=args.grid, cols=args.grid, spacing=args.pitch, seed=7 + rank,
                                    noise_px=0.2, first_view_global=rank * args.views)
     flat = scene.flat
     init_intr, init_view = flat.intr.copy(), flat.view_pose.copy()
@@ -127,13 +129,13 @@ def main():
     # sustained fp64 work it settles at ~0.16 ms (tools/exp_modeb_warm.py).  Both are reported; `ms_per_pass` is the settled one.
     ms_b_first = h.normal_eq_timed(2, 10)
     ms_b = h.normal_eq_timed(200, 50)
-    flop_per_obs = 608
+    flop_per_obs, valu_per_obs = 605, 374  # tools/isa_mix.py on the shipped kernel (profiles/r03_modeb_isa_mix.txt)
     mode_b = {"kernel": "k_ne_shared<DirectForm<INTRINSIC,PINHOLE_BC,2 parts>> + k_tile_sum", "ms_per_pass": ms_b,
               "ms_per_pass_right_after_mode_a": ms_b_first, "timing": "200 warm-up passes, 50 timed (HIP events); the other figure: 2 + 10",
               "bound": "fp64 vector issue",
-              "flop_per_obs": flop_per_obs, "valu_instructions_per_obs": 382, "achieved_TFLOPs": flop_per_obs * n_obs / (ms_b * 1e-3) / 1e12,
+              "flop_per_obs": flop_per_obs, "valu_instructions_per_obs": valu_per_obs, "achieved_TFLOPs": flop_per_obs * n_obs / (ms_b * 1e-3) / 1e12,
               "peak_TFLOPs": 78.6, "frac": flop_per_obs * n_obs / (ms_b * 1e-3) / 78.6e12,
-              "issue_slots_frac_at_2p4GHz": 382 * 4 * (n_obs / 64 / 1024) / (ms_b * 1e-3 * 2.4e9), "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
+              "issue_slots_frac_at_2p4GHz": valu_per_obs * 4 * (n_obs / 64 / 1024) / (ms_b * 1e-3 * 2.4e9), "hbm_GBs": 16 * n_obs / (ms_b * 1e-3) / 1e9}
 
     # ---- LM wall-clock to tolerance on the same data (all ranks; RCCL all-reduce when world > 1) -----
     # Runs on a worker thread under a watchdog: a collective that never completes (the multi-rank RCCL path
@@ -147,20 +149,14 @@ def main():
             handle.set_allreduce(_allreduce, world, rank)
             return f"host callback over torch.distributed {dist.get_backend()} (rehearsal)"
         if world > 1:
-            try:  # RCCL-native: ncclAllReduce of the device-resident packed system on the engine's stream
-                uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    uid = torch.tensor(list(optim.rccl_unique_id()), dtype=torch.uint8, device="cuda")
-                dist.broadcast(uid, 0)
-                handle.init_rccl(bytes(uid.cpu().numpy().tolist()), world, rank)
-                return "rccl (libcalibba ncclAllReduce, device-resident pack)"
-            except Exception as ex:  # fall back to the host-callback transport over torch.distributed (RCCL)
-                def _allreduce(arr):
-                    t = torch.from_numpy(arr).cuda()
-                    dist.all_reduce(t)
-                    arr[...] = t.cpu().numpy()
-                handle.set_allreduce(_allreduce, world, rank)
-                return f"host callback over torch.distributed nccl ({type(ex).__name__})"
+            # RCCL-native: ncclAllReduce of the device-resident packed system on the engine's stream.  A failure here is a failure of
+            # the run (no host-staged fall-back: the figure would describe another transport than the one it is labelled with).
+            uid = torch.zeros(capi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.tensor(list(optim.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            handle.init_rccl(bytes(uid.cpu().numpy().tolist()), world, rank)
+            return "rccl (libcalibba ncclAllReduce, device-resident pack)"
         return "none (1 rank)"
 
     def timed_solve(handle):
@@ -218,7 +214,13 @@ def main():
                                    "intr_err_max": float(np.abs(sc3.flat.intr - sc3.gt_intr)[:, :4].max()), "allreduce": transport3,
                                    "allreduce_calls": xs3["allreduce_calls"], "allreduce_bytes": 8 * xs3["allreduce_doubles"],
                                    "speculation": {k: xs3[k] for k in ("speculative_steps", "speculation_hits", "speculation_misses", "rejected_steps")},
-                                   "mode_b_ms_per_pass_this_rank": ms_b3, "obs_this_rank": int(sc3.flat.n_obs), "scene_gen_s": gen3}
+                                   "mode_b_ms_per_pass_this_rank": ms_b3, "obs_this_rank": int(sc3.flat.n_obs), "scene_gen_s": gen3,
+                                   # k_ne_shared<MomentForm<PINHOLE_BC, 4 parts>>: 616 FLOP in 410 vector instructions per observation
+                                   # (tools/isa_mix.py, profiles/r03_modeb_isa_mix.txt), against the 78.6 TFLOP/s fp64 vector peak
+                                   "mode_b": {"kernel": "k_ne_shared<MomentForm<PINHOLE_BC,4 parts>> + k_tile_sum + k_mom_expand", "flop_per_obs": 616,
+                                              "valu_instructions_per_obs": 410, "bound": "fp64 vector issue",
+                                              "achieved_TFLOPs": 616 * int(sc3.flat.n_obs) / (ms_b3 * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
+                                              "frac": 616 * int(sc3.flat.n_obs) / (ms_b3 * 1e-3) / 78.6e12}}
         except Exception as ex:
             lm_box["lm_strong"] = {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -279,6 +281,28 @@ def main():
         cpu = {"value": sample_obs * reps / secs, "unit": "evals/s", "cores": cores, "kind": "port",
                "sample": f"{sample_views} views x {args.grid * args.grid} pts x {reps} passes of the oracle's Jet<17> "
                          f"autodiff residual+Jacobian, one residual block per view, {cores} threads over views"}
+        # The second half of the metric, "LM wall-clock to tolerance", on the same host: the oracle's LM (the restated Ceres path:
+        # Jet autodiff per residual block, dense normal equations, the same trust-region rules and epsilon; ceresutils.h:27-43) at 1
+        # thread and at all threads, on the exact configs[0] problem and on a bounded sample of this workload (the dense oracle
+        # cannot hold all 1000 views: 64 views x 10000 points, the same scene generator, pitch and noise).
+        def oracle_lm(flat_cpu, threads):
+            f2 = copy.deepcopy(flat_cpu)
+            o2 = capi.default_options()
+            o2.compute_covariance = 0
+            t1 = time.perf_counter()
+            s2 = helpers.oracle_solve(orc, f2, o2, threads=threads)
+            return {"wall_s": time.perf_counter() - t1, "iterations": int(s2.iterations), "success": bool(s2.success), "final_cost": float(s2.final_cost)}
+        try:
+            sc1c = synth.scene_intrinsics(20, noise_px=0.2)
+            sc2c = synth.scene_intrinsics(64, rows=args.grid, cols=args.grid, spacing=args.pitch, seed=7, noise_px=0.2)
+            cpu["lm"] = {"kind": "port (oracle/lm.hpp: restated Ceres trust-region LM, dense, Jet autodiff)", "epsilon": float(capi.default_options().epsilon),
+                         "c1": {"workload": "pinhole intrinsics, 20 views x 88 pts (configs[0]), the problem of lm_c1",
+                                "threads_1": oracle_lm(sc1c.flat, 1), f"threads_{cores}": oracle_lm(sc1c.flat, cores)},
+                         "c2_sample": {"workload": f"64 of the {args.views} views x {args.grid * args.grid} pts of this workload (pitch {args.pitch} m)",
+                                       "observations": int(sc2c.flat.n_obs), "threads_1": oracle_lm(sc2c.flat, 1),
+                                       f"threads_{cores}": oracle_lm(sc2c.flat, cores)}}
+        except Exception as ex:
+            cpu["lm"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         out = {
@@ -291,10 +315,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_metric": "lm_strong.wall_s",  # the strong-scaling figure of the north-star (configs[2] split over the ranks);
+                                                   # `value` is the weak scaling of a kernel with no collective
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"pinhole+Brown-Conrady intrinsics, {args.views} views x {args.grid * args.grid} pts per GPU, fp64",
+            "config": {"workload": f"pinhole+Brown-Conrady intrinsics, {args.views} views x {args.grid * args.grid} pts per GPU "
+                                   f"({args.grid} x {args.grid} board, pitch {args.pitch} m), fp64",
                        "views_per_gpu": args.views, "points_per_view": args.grid * args.grid, "tangent_columns": P,
                        "parallelism": f"views sharded over {world} GPU(s)"},
             "roofline": roofline,
@@ -308,9 +335,12 @@ def main():
         print(json.dumps(out), flush=True)
     if lm_hung:  # a stuck collective cannot be cancelled: the metric line is out; leave without touching the GPU again, and
         os._exit(3)  # not as a success
+    lm_failed = any(isinstance(x, dict) and "error" in x for x in (lm, lm_strong))
     h.close()
     if dist is not None:
         dist.destroy_process_group()
+    if lm_failed:  # (e.g. the RCCL transport could not be set up): the metric line is out, the run is not a success
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <set>
 
 #include "engine.hpp"
@@ -1132,7 +1133,28 @@ struct HipBackend final : Backend {
             }
         }
         if (*seq < want) {
-            CBA_HIP(hipEventSynchronize(st.ctl_done));
+            if (!e.rccl_comm) {
+                CBA_HIP(hipEventSynchronize(st.ctl_done));
+            } else {
+                // A collective is queued in front of the controller: a peer that failed (threw out of its solve and aborted its
+                // communicator, died, hung) must not leave this rank waiting for ever.  Poll the event, watch the communicator's
+                // asynchronous error state and a deadline; on either, abort the communicator (which releases the stream) and fail.
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t q = hipEventQuery(st.ctl_done);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) CBA_HIP(q);
+                    ncclResult_t async = ncclSuccess;
+                    (void)ncclCommGetAsyncError(reinterpret_cast<ncclComm_t>(e.rccl_comm), &async);
+                    const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(st.rccl_timeout_s);
+                    if (async != ncclSuccess || late) {
+                        rccl_abort(e);
+                        throw HipError(late ? "RCCL exchange: no progress within the deadline (a peer rank failed or hung); communicator aborted"
+                                            : std::string("RCCL exchange failed on a peer: ") + ncclGetErrorString(async) + "; communicator aborted");
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+            }
             if (*seq < want) throw HipError("LM controller: the control record did not arrive");
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1285,6 +1307,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     if (const char* env = std::getenv("CBA_LM_CTL")) st->lm_ctl_mode = std::atoi(env) != 0;
     if (const char* env = std::getenv("CBA_LM_CTL_POLL_US")) st->ctl_poll_us = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_PRELAUNCH")) st->ctl_prelaunch = std::atoi(env);
+    if (const char* env = std::getenv("CBA_RCCL_TIMEOUT_S")) st->rccl_timeout_s = std::max(1, std::atoi(env));
     warm_lm_ctl();
     if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_RESIDENT_MAX_OBS")) st->resident_max_obs = std::atoll(env);
@@ -1340,6 +1363,16 @@ void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank) {
     e.rccl_comm = comm;
     e.n_ranks = n_ranks;
     e.rank = rank;
+}
+
+// the abort path: this rank cannot go on (an exception in its solve, a peer that no longer answers); ncclCommAbort tears the
+// communicator down without waiting for outstanding collectives, which also lets the peers' pending collectives fail instead of
+// hanging (they see it through ncclCommGetAsyncError in ctl_wait, or run into their own deadline)
+void rccl_abort(Engine& e) {
+    if (e.rccl_comm) {
+        (void)ncclCommAbort(reinterpret_cast<ncclComm_t>(e.rccl_comm));
+        e.rccl_comm = nullptr;
+    }
 }
 
 void rccl_destroy(Engine& e) {
@@ -1420,7 +1453,15 @@ void solve_lm(Engine& e, const cba_options& o, cba_summary* out) {
     }
     HipBackend be(e, *lm_state(e));
     LMDriver drv = make_driver(e, be);
-    drv.solve(o, out);
+    try {
+        drv.solve(o, out);
+    } catch (...) {
+        // this rank leaves the solve: its peers may be inside (or about to enter) the collective of the same step - abort the
+        // communicator so that they fail too instead of waiting for a contribution that will never come
+        e.gate = nullptr;
+        rccl_abort(e);
+        throw;
+    }
     {
         const ExchangeStats& x = drv.exchange_stats();
         int64_t* xs = lm_state(e)->xs;

@@ -2,6 +2,7 @@
 // of the solve that is a handful of kFLOP per LM step and stays on the host next to the accept /
 // reject control flow.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -136,6 +137,42 @@ inline void chol_solve(const std::vector<double>& L, int n, double* b) {
         for (int k = 0; k < i; ++k) b[k] -= li[k] * x;
     }
 }
+// Extreme eigenvalues of a symmetric n x n matrix (row-major, destroyed) by cyclic Jacobi rotations: the reduced system of a
+// covariance request is a few hundred wide at most and this runs once per request, off every hot path.
+inline void sym_eig_minmax(std::vector<double>& A, int n, double* lmin, double* lmax) {
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? dia : off) += A[static_cast<size_t>(i) * n + j] * A[static_cast<size_t>(i) * n + j];
+        if (off <= 1e-30 * dia) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[static_cast<size_t>(p) * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[static_cast<size_t>(q) * n + q] - A[static_cast<size_t>(p) * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {  // columns p, q
+                    const double akp = A[static_cast<size_t>(k) * n + p], akq = A[static_cast<size_t>(k) * n + q];
+                    A[static_cast<size_t>(k) * n + p] = c * akp - sn * akq;
+                    A[static_cast<size_t>(k) * n + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {  // rows p, q
+                    const double apk = A[static_cast<size_t>(p) * n + k], aqk = A[static_cast<size_t>(q) * n + k];
+                    A[static_cast<size_t>(p) * n + k] = c * apk - sn * aqk;
+                    A[static_cast<size_t>(q) * n + k] = sn * apk + c * aqk;
+                }
+            }
+    }
+    double lo = A[0], hi = A[0];
+    for (int i = 1; i < n; ++i) {
+        lo = std::min(lo, A[static_cast<size_t>(i) * n + i]);
+        hi = std::max(hi, A[static_cast<size_t>(i) * n + i]);
+    }
+    *lmin = lo;
+    *lmax = hi;
+}
+
 // inverse of an SPD matrix from its Cholesky factor
 inline void chol_inverse(const std::vector<double>& L, int n, std::vector<double>& inv) {
     inv.assign(static_cast<size_t>(n) * n, 0.0);

@@ -258,6 +258,7 @@ void engine_allreduce(Engine& e, double* host_buf, int64_t count);
 void rccl_unique_id(uint8_t* id);
 void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank);
 void rccl_destroy(Engine& e);
+void rccl_abort(Engine& e);  // ncclCommAbort: this rank leaves a multi-rank solve abnormally; the peers' collectives fail instead of hanging
 void planar_pose_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, int num_radial, double* pose7, const cba_options* o, cba_summary* summaries,
                        double* distortion, double* rms, double* cov, int device);

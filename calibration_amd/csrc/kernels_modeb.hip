@@ -23,6 +23,13 @@
 #include "reproj_math.hpp"
 #include "wave_reduce.hpp"
 
+#ifndef CBA_NE_MOM4_MINW
+#define CBA_NE_MOM4_MINW 1
+#endif
+#ifndef CBA_NE_DIRECT_MINW
+#define CBA_NE_DIRECT_MINW 1
+#endif
+
 namespace cba {
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
@@ -32,6 +39,7 @@ template <int CHAIN, int MODEL, class SPLIT, typename T>
 struct DirectForm {
     using D = DirectRows<CHAIN, MODEL>;
     static constexpr int NROW = D::N, NPARTS = SPLIT::parts, NTOT = D::PL * (D::PL + 1) / 2 + D::PL + 1;
+    static constexpr int MINW = CBA_NE_DIRECT_MINW;
     static constexpr int count(int part) { return SPLIT::count(D::PL, part); }
     static __device__ __forceinline__ int entry(int part, int l) { return SPLIT::entry(D::PL, part, l); }
     static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
@@ -43,10 +51,11 @@ struct DirectForm {
     }
 };
 
-template <int MODEL, int NP, typename T>
+template <int MODEL, int NP, typename T, int MW = 1>
 struct MomentForm {
     static constexpr int PI = IntrSize<MODEL>::value;
     static constexpr int NROW = MomRows<PI>::N, NPARTS = NP, NTOT = MomLayout<PI>::N;
+    static constexpr int MINW = MW;
     static constexpr int count(int part) { return MomSplit<PI, NP>::T.count[part]; }
     static __device__ __forceinline__ int entry(int part, int l) { return MomSplit<PI, NP>::T.entry[part][l]; }
     static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
@@ -86,18 +95,21 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
     for (int g = 0; g < n_groups; ++g) {
         const int j = (g * NP + PART) * 64 + lane;
         v2f64 (*sh)[NR2][64] = shb + (NBUF == 2 ? (g & 1) * NP : 0);
-        T xn = T(0), yn = T(0), un = T(0), vn = T(0);
-        if (!ONE && j + 64 * NP < t.count) {  // the loads of the next group's own chunk, before this group's arithmetic
-            const int64_t i = t.start + j + 64 * NP, k2 = t.xy_start + j + 64 * NP;
-            xn = X[k2]; yn = Y[k2]; un = u[i]; vn = v[i];
-        }
+        // The loads of the next group's own chunk are issued INTO the registers of the current one as soon as those are dead
+        // (u, v after the rows, x, y after the own chunk's accumulation): the prefetch costs no registers of its own (8 fewer
+        // than holding both sets: the general moment-form kernel fits 168 and a third workgroup lives on the CU), and the loads
+        // still have the barrier and the other chunks' accumulation to arrive.
+        const bool more = !ONE && j + 64 * NP < t.count;
+        const int64_t in = t.start + j + 64 * NP, k2n = t.xy_start + j + 64 * NP;
         if (j < t.count) {
             double w[2 * NR2];
             FORM::rows(bcp, ip, sp, xc, yc, uc, vc, w);
             if (NROW & 1) w[NROW] = 0.0;
+            if (more) { uc = u[in]; vc = v[in]; }
 #pragma unroll
             for (int k = 0; k < NR2; ++k) sh[PART][k][lane] = v2f64{w[2 * k], w[2 * k + 1]};
             FORM::template accumulate<PART>(w, static_cast<double>(xc), static_cast<double>(yc), acc);
+            if (more) { xc = X[k2n]; yc = Y[k2n]; }
         }
         if (!(ABL & 1)) __syncthreads();  // every wavefront's rows of this group are in LDS
 #pragma unroll
@@ -114,7 +126,6 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
             }
         }
         if (NBUF == 1 && !(ABL & 1) && !ONE) __syncthreads();  // before the next group overwrites the rows
-        xc = xn; yc = yn; uc = un; vc = vn;
     }
     bool owner;
     const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
@@ -129,8 +140,10 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 }
 
 // one workgroup of FORM::NPARTS wavefronts per tile
+// MINW: wavefronts per SIMD the kernel is compiled for (0: whatever its registers allow).  A form within a few registers of the
+// next occupancy step is compiled for that step (FORM::MINW): its row buffers allow the extra workgroup on the CU.
 template <class FORM, int NBUF, typename T, int ABL = 0, bool ONE = false>
-__global__ __launch_bounds__(64 * FORM::NPARTS) void k_ne_shared(const double* __restrict__ gate, const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
+__global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(const double* __restrict__ gate, const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
                                                                   const T* __restrict__ Y, const T* __restrict__ u, const T* __restrict__ v,
@@ -199,10 +212,11 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
         if (!e.modeb_moments) return false;
         if (e.model == CAM_PINHOLE_BC) {
             if ((variant & 15) == 2) launch_both<MomentForm<CAM_PINHOLE_BC, 2, double>, MomentForm<CAM_PINHOLE_BC, 2, float>>(e, rows);
+            else if (variant == 36) launch_both<MomentForm<CAM_PINHOLE_BC, 4, double, 3>, MomentForm<CAM_PINHOLE_BC, 4, float>>(e, rows);  // capped at 168 registers
             else if ((variant & 15) == 4) launch_both<MomentForm<CAM_PINHOLE_BC, 4, double>, MomentForm<CAM_PINHOLE_BC, 4, float>>(e, rows);
             else if ((variant & 15) == 5) launch_both<MomentForm<CAM_PINHOLE_BC, 5, double>, MomentForm<CAM_PINHOLE_BC, 5, float>>(e, rows);
             else if (variant & 16) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>, 2>(e, rows);
-            else if (variant >= 32 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
+            else if (variant >= 32 && variant != 36 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
                 using F = MomentForm<CAM_PINHOLE_BC, 3, double>;
                 const dim3 g(static_cast<unsigned>(e.n_tilesB)), b(64 * 3);
 #define CBA_ABL(A) hipLaunchKernelGGL((k_ne_shared<F, 1, double, A>), g, b, 0, e.stream, e.gate, e.tilesB.p, e.n_tilesB, e.bc.p, e.intr[e.active].p, e.sd.p, \

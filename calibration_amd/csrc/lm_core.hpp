@@ -674,8 +674,13 @@ class LMDriver {
             ar_(buf.data(), static_cast<int64_t>(buf.size()));
             assemble_shared(buf, Hcc, gc);
         }
-        // ceres::Covariance (SPARSE_QR): a column is dependent when its R diagonal is below
-        // 20 (m + n) eps max_j |J_j| (SuiteSparseQR default tolerance, third-party, restated)
+        // Rank test.  The reference-layout matrix (cba_reproj_covariance, ceresutils.h:69-126) mimics what ceres::Covariance does with
+        // its default SPARSE_QR: a column is dependent when its R diagonal is below 20 (m + n) eps max_j |J_j| (SuiteSparseQR's
+        // default tolerance, third-party, restated).  That tolerance grows with the ROW count and says "rank deficient" for any
+        // problem of 1e8 observations.  The shared-block covariance (cba_reproj_covariance_shared) is this library's own API with no
+        // reference counterpart to be faithful to: it tests what actually matters for the inverse it returns, the reciprocal
+        // condition number of the Jacobi-scaled reduced system against ceres::Covariance::Options::min_reciprocal_condition_number
+        // = 1e-14 (and positive definiteness of every per-view block).
         double cmax = 0;
         for (int i = 0; i < n; ++i) cmax = std::max(cmax, std::sqrt(Hcc[static_cast<size_t>(i) * n + i]));
         for (int v = 0; v < s_.n_views; ++v)
@@ -720,8 +725,9 @@ class LMDriver {
             }
             std::vector<double> L = H;
             if (!chol_inplace(L, 6)) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
-            for (int i = 0; i < 6; ++i)
-                if (L[i * 6 + i] <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
+            if (!shared_only)
+                for (int i = 0; i < 6; ++i)
+                    if (L[i * 6 + i] <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (view block)");
             std::vector<double> Hi;
             chol_inverse(L, 6, Hi);
             std::memcpy(&Hinv[static_cast<size_t>(fv) * 36], Hi.data(), sizeof(double) * 36);
@@ -743,10 +749,25 @@ class LMDriver {
         for (size_t i = 0; i < S0.size(); ++i) S0[i] -= Sloc[i];
         std::vector<double> Lc = S0, Scc;
         if (na > 0) {
+            if (shared_only) {  // reciprocal condition number of the Jacobi-scaled reduced system (see the rank-test note above)
+                std::vector<double> Ss(S0.size());
+                for (int a = 0; a < na; ++a)
+                    for (int b = 0; b < na; ++b) {
+                        const double da = S0[static_cast<size_t>(a) * na + a], db = S0[static_cast<size_t>(b) * na + b];
+                        if (!(da > 0.0) || !(db > 0.0)) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
+                        Ss[static_cast<size_t>(a) * na + b] = S0[static_cast<size_t>(a) * na + b] / std::sqrt(da * db);
+                    }
+                double lmin = 0, lmax = 0;
+                sym_eig_minmax(Ss, na, &lmin, &lmax);
+                if (!(lmin > 0.0) || lmin / lmax < 1e-14)
+                    throw std::runtime_error("covariance: rank deficient Jacobian (reduced system: reciprocal condition number below 1e-14)");
+            }
             if (!chol_inplace(Lc, na)) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
-            double dmin = 1e300;
-            for (int i = 0; i < na; ++i) dmin = std::min(dmin, Lc[static_cast<size_t>(i) * na + i]);
-            if (dmin <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
+            if (!shared_only) {
+                double dmin = 1e300;
+                for (int i = 0; i < na; ++i) dmin = std::min(dmin, Lc[static_cast<size_t>(i) * na + i]);
+                if (dmin <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
+            }
             chol_inverse(Lc, na, Scc);
         }
         // tangent covariance: [shared active (na) | free views (6 each)]

@@ -72,6 +72,7 @@ struct HipLMState {
     PinnedBuf<double> ctl_rec;  // [control record CS_COUNT | staging of the scalars CS_COUNT | staging of the start point pk_size]
     CtlView ctl_view{};
     int ctl_n = -1;             // reduced size the buffers above were laid out for
+    int rccl_timeout_s = 120;   // ctl_wait gives a step's collective this long before it aborts the communicator (CBA_RCCL_TIMEOUT_S)
     int ctl_prelaunch = 1;      // queue the head of the next step behind the controller before its decision is known (CBA_LM_PRELAUNCH)
     int ctl_poll_us = 400;      // how long ctl_wait polls the record before it sleeps on the stream
     int lm_ctl_mode = 1;        // 1 = the controller form of the host-driven iteration (default), 0 = the host-side form (CBA_LM_CTL)

@@ -188,6 +188,7 @@ __device__ __forceinline__ void direct_accumulate(const double* w, double* acc) 
         for (int j = 0; j < D::PI; ++j) Ju[D::OI + j] = R::u_live(j) ? w[n++] : (j == 2 ? 1.0 : 0.0);
 #pragma unroll
         for (int j = 0; j < D::PI; ++j) Jv[D::OI + j] = R::v_live(j) ? w[n++] : (j == 3 ? 1.0 : 0.0);
+        Jv[D::OI + 1] = Ju[D::OI + 4];  // d v / d fy = d u / d skew (not shipped twice)
     }
     int e = 0;
 #pragma unroll

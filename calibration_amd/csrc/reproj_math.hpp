@@ -434,13 +434,14 @@ CBA_HD double mom_expand_entry_T(const double* mom, const double G[3][36], const
 // The per-observation quantities the moment sums are built from ("moment rows"), in the order
 //   w = [ r_u, r_v | du[3] | dv[3] | the intrinsics entries of the u row that are not structural constants | those of the v row ]
 // Of the intrinsics columns [fx fy cx cy skew ...] the u row has no fy / cy entry and d u / d cx = 1, the v row has no fx / cx /
-// skew entry and d v / d cy = 1 (both camera models): 2 * PI - 7 live entries.  A wavefront that evaluated an observation hands
-// exactly these MomRows<PI>::N numbers to the wavefronts that accumulate other parts of the moment row (kernels_modeb.hip).
+// skew entry and d v / d cy = 1 (both camera models), and d v / d fy IS d u / d skew (the same expression, yd + m0y: reproj_core):
+// 2 * PI - 8 live entries.  A wavefront that evaluated an observation hands exactly these MomRows<PI>::N numbers to the wavefronts
+// that accumulate other parts of the moment row (kernels_modeb.hip); the receiver takes Jv[fy] from Ju[skew].
 template <int PI>
 struct MomRows {
-    static constexpr int NU = PI - 3, NV = PI - 4, N = 8 + NU + NV;
+    static constexpr int NU = PI - 3, NV = PI - 5, N = 8 + NU + NV;
     static constexpr bool u_live(int c) { return !(c == 1 || c == 2 || c == 3); }
-    static constexpr bool v_live(int c) { return !(c == 0 || c == 2 || c == 3 || c == 4); }
+    static constexpr bool v_live(int c) { return !(c == 0 || c == 1 || c == 2 || c == 3 || c == 4); }
 };
 
 // Which wavefront ("part") of a Mode B workgroup keeps which entry of the moment row, and in which of its accumulators.
@@ -556,6 +557,7 @@ CBA_HD void mom_accumulate(const double* w, double x, double y, double* acc) {
         int n = 8;
         for (int j = 0; j < PI; ++j) Jui[j] = R::u_live(j) ? w[n++] : (j == 2 ? 1.0 : 0.0);
         for (int j = 0; j < PI; ++j) Jvi[j] = R::v_live(j) ? w[n++] : (j == 3 ? 1.0 : 0.0);
+        Jvi[1] = Jui[4];  // d v / d fy = d u / d skew (not shipped twice)
     }
     const double m[3] = {1.0, x, y};
     const double mm[6] = {1.0, x, y, x * x, x * y, y * y};

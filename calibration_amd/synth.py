@@ -264,10 +264,14 @@ def scene_extrinsics_shard(n_views_total, v0, v1, n_cams=8, rows=50, cols=100, s
 
 
 def scene_bundle(n_poses=25, n_cams=1, rows=8, cols=11, spacing=0.02, model=capi.CAMERA_PINHOLE_BC, seed=2024,
-                 noise_px=0.0, distortion=False, init="perturbed") -> Scene:
-    """C4-shaped hand-eye bundle (bundle_test.cpp:9-81 recipe, n_cams cameras with small offsets)."""
+                 noise_px=0.0, distortion=False, init="perturbed", tau=None, max_tilt_deg=25.0, jitter=0.08, depth_spread=0.0) -> Scene:
+    """C4-shaped hand-eye bundle (bundle_test.cpp:9-81 recipe, n_cams cameras with small offsets).  tau / max_tilt_deg / jitter /
+    depth_spread shape the conditioning as in scene_intrinsics (a WELL-CONDITIONED Scheimpflug bundle: scene_bundle_wide)."""
     rng = np.random.default_rng(seed)
     cams = [camera_gt(model, distortion) for _ in range(n_cams)]
+    if tau is not None and model == capi.CAMERA_SCHEIMPFLUG:
+        for cam in cams:
+            cam[10:12] = tau
     g_T_c = [make_pose(np.array([0.03 + 0.05 * c, 0.01 * c, 0.12]), np.array([0.0, 1.0, 0.0]), np.deg2rad(8.0 - 3.0 * c))
              for c in range(n_cams)]
     b_T_t = make_pose(np.array([0.5, -0.1, 0.8]), np.array([1.0, 0.0, 0.0]), np.deg2rad(14.0))
@@ -275,7 +279,7 @@ def scene_bundle(n_poses=25, n_cams=1, rows=8, cols=11, spacing=0.02, model=capi
     # robot poses: gripper looks at the target from ~1 m with random tilt
     b_T_g = []
     for _ in range(n_poses):
-        c_T_t = random_view_poses(1, rng, dist=1.0, max_tilt_deg=25.0, jitter=0.08)[0]
+        c_T_t = random_view_poses(1, rng, dist=1.0, max_tilt_deg=max_tilt_deg, jitter=jitter, depth_spread=depth_spread)[0]
         b_T_g.append(b_T_t @ inv(c_T_t) @ inv(g_T_c[0]))
     blocks, bcam, btg = [], [], []
     for T in b_T_g:
@@ -294,6 +298,14 @@ def scene_bundle(n_poses=25, n_cams=1, rows=8, cols=11, spacing=0.02, model=capi
                        np.stack([pose_from_matrix(T) for T in g0]), None, pose_from_matrix(bt0), np.stack(btg))
     return Scene(flat, np.stack(cams), gt_cam_pose=np.stack([pose_from_matrix(T) for T in g_T_c]),
                  gt_target_pose=pose_from_matrix(b_T_t), meta=dict(kind="bundle", n_poses=n_poses, n_cams=n_cams, seed=seed))
+
+
+def scene_bundle_wide(n_poses=24, n_cams=2, model=capi.CAMERA_SCHEIMPFLUG, seed=3, noise_px=0.2, **kw) -> Scene:
+    """A WELL-CONDITIONED hand-eye bundle for the Scheimpflug model (cf. scene_intrinsics_wide): a 0.65 m x 0.45 m board seen from
+    ~1 m, tilts up to 45 degrees, distances spread over 0.6 .. 1.4 of the nominal one, sensor tilt (0.2, -0.15) rad."""
+    args = dict(rows=10, cols=14, spacing=0.05, tau=(0.2, -0.15), max_tilt_deg=45.0, jitter=0.15, depth_spread=0.4, distortion=True)
+    args.update(kw)
+    return scene_bundle(n_poses, n_cams, model=model, seed=seed, noise_px=noise_px, **args)
 
 
 def shard_views(flat: FlatProblem, rank: int, world: int) -> FlatProblem:

@@ -114,16 +114,17 @@ CASES = [
     ("intr", 0, {}, {}, 1e-9),
     ("intr", 0, dict(noise_px=0.2), {}, 1e-9),
     ("intr", 0, {}, dict(optimize_skew=1), 5e-9),  # free skew: conditioning ~1e7 puts rounding at the 1e-9 edge
-    ("intr", 1, {}, {}, 1e-6),
+    ("intr", 1, {}, {}, 1e-6),  # (narrow scene: the flat valley is demonstrated in test_scheimpflug_parity_gap_lies_in_the_flat_valley)
     ("ext", 0, {}, {}, 1e-9),
     ("ext", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
     ("ext", 0, dict(noise_px=0.2), dict(optimize_extrinsics=0), 1e-9),
-    ("ext", 1, {}, {}, 1e-6),
+    ("ext", 1, {}, {}, 1e-9),
+    ("ext", 1, dict(noise_px=0.2), {}, 1e-9),
     ("bundle", 0, {}, dict(optimize_intrinsics=1), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, huber_delta=-1.0), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0, optimize_target_pose=0), 1e-9),
-    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-6),
+    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-9),
 ]
 
 
@@ -159,6 +160,21 @@ def test_scheimpflug_well_conditioned_scene_meets_the_1e9_bar(gpu_lib, oracle, s
     assert helpers.param_diff(a.flat, b.flat) <= 1e-9, helpers.param_diff(a.flat, b.flat)
 
 
+@pytest.mark.parametrize("seed,okw", [(3, dict(optimize_intrinsics=1)), (5, dict(optimize_intrinsics=1, huber_delta=-1.0)), (7, dict(optimize_intrinsics=1))])
+def test_scheimpflug_bundle_chain_meets_the_1e9_bar_with_noise(gpu_lib, oracle, seed, okw):
+    """The two-pose BUNDLE chain with the Scheimpflug model and 0.2 px noise at the north-star's bar: on a hand-eye bundle whose
+    data determine the sensor tilt (synth.scene_bundle_wide: 0.65 m board at ~1 m, tilts up to 45 degrees, depth spread, tilt
+    0.2 rad) the HIP engine and the oracle agree to 1e-9 - in fact to rounding.  (The EXTRINSIC chain meets it on the standard noisy
+    scene: CASES.)  Reference: include/calib/models/scheimpflug.h:139-181 through src/estimation/residuals/bundleresidual.h:36-56."""
+    a, b = synth.scene_bundle_wide(seed=seed), synth.scene_bundle_wide(seed=seed)
+    o = options(epsilon=1e-12, **okw)
+    sa = helpers.oracle_solve(oracle, a.flat, o, threads=16)
+    sb = _gpu_solver(b.flat, o)
+    assert sa.success and sb.success and abs(sb.iterations - sa.iterations) <= 1
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-9, helpers.param_diff(a.flat, b.flat)
+
+
 @pytest.mark.parametrize("seed", [7, 11, 13])
 def test_scheimpflug_parity_gap_lies_in_the_flat_valley(gpu_lib, oracle, seed):
     """The reference's test geometry leaves the Scheimpflug tilt / principal point / focal length valley nearly flat (condition
@@ -176,6 +192,36 @@ def test_scheimpflug_parity_gap_lies_in_the_flat_valley(gpu_lib, oracle, seed):
     assert rep["kappa"] > 1e8 and gap <= 1e-6, (rep, gap)
     if gap > 1e-10:
         assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, (rep, gap)
+
+
+PINNED_FUZZ = [  # found by tools/fuzz_gpu.py in round 2 (profiles/r02_fuzz_*.json): parameter gaps far above the 1e-9 bar
+    dict(kind="intr", model=1, seed=4976, noise=0.5, okw=dict(huber_delta=0.3, optimize_skew=0), nv=7, nc=2, grid=(7, 11)),
+    dict(kind="intr", model=0, seed=705088, noise=0.1, okw=dict(huber_delta=3.0, optimize_skew=1), nv=6, nc=2, grid=(5, 5)),
+    dict(kind="bundle", model=1, seed=32942, noise=0.1, okw=dict(huber_delta=-1.0, optimize_skew=0, optimize_intrinsics=1, optimize_extrinsics=1,
+                                                                  optimize_target_pose=0), nv=8, nc=3, grid=(4, 9)),
+]
+
+
+@pytest.mark.parametrize("rec", PINNED_FUZZ, ids=lambda r: f"{r['kind']}-{r['seed']}")
+def test_pinned_fuzz_disagreements_are_conditioning_not_arithmetic(gpu_lib, oracle, hostmath, rec):
+    """The random sweep's worst cases, pinned: the HIP engine and the oracle end 1e-6 .. 1e-3 apart in parameters.  The test does not
+    accept that on faith: the gap must be BENIGN by the rule the sweep applies to every case (helpers.gap_is_benign) - same
+    termination, >= 95 % of the Jacobi-scaled difference inside the three weakest eigen-directions of a Hessian with condition
+    number > 1e6, no constant coordinate moved, and a cost difference no larger than twice what that displacement predicts."""
+    rows, cols = rec["grid"]
+    mk = {"intr": lambda: synth.scene_intrinsics(rec["nv"], rows=rows, cols=cols, spacing=0.08, model=rec["model"], noise_px=rec["noise"], seed=rec["seed"]),
+          "ext": lambda: synth.scene_extrinsics(rec["nv"], max(2, rec["nc"]), rows=rows, cols=cols, spacing=0.08, model=rec["model"], noise_px=rec["noise"], seed=rec["seed"]),
+          "bundle": lambda: synth.scene_bundle(rec["nv"] + 4, rec["nc"], rows=rows, cols=cols, spacing=0.04, model=rec["model"], noise_px=rec["noise"], seed=rec["seed"])}[rec["kind"]]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **rec["okw"])
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+    assert sa.termination == sb.termination
+    gap = helpers.param_diff(a.flat, b.flat)
+    if gap > 1e-9:
+        rep = helpers.solution_gap_report(oracle, hostmath, a.flat, b.flat, o)
+        assert helpers.gap_is_benign(rep, sa.final_cost, sb.final_cost), (gap, rep, sa.final_cost, sb.final_cost)
 
 
 @pytest.mark.parametrize("kind,model,seed", [("intr", 0, 7), ("ext", 0, 9), ("intr", 0, 19), ("ext", 0, 23), ("intr", 0, 4)])
@@ -439,8 +485,9 @@ def test_planar_pose_batch_matches_oracle(gpu_lib, oracle):
         views.append(synth.render_view(cam, T, grid, noise_px=0.2, rng=rng))
         inits.append(synth.perturb_pose(T, rng, 1.5, 0.02))
     for nr in (0, 2):
-        out = optim.optimize_planar_pose_batch(views, K, inits, optim.PlanarPoseOptions(num_radial=nr))
-        o = options()
+        # epsilon 1e-12 on both sides: the bar measures arithmetic parity, not where each solver happened to stop (module docstring)
+        out = optim.optimize_planar_pose_batch(views, K, inits, optim.PlanarPoseOptions(core=optim.OptimOptions(epsilon=1e-12), num_radial=nr))
+        o = options(epsilon=1e-12)
         for i, (vw, T0) in enumerate(zip(views, inits)):
             X, Y, u, v = (np.ascontiguousarray(vw[:, k]) for k in range(4))
             p, s, d, rms, cov = helpers.pose6_of(T0), capi.CbaSummary(), np.zeros(nr + 2), C.c_double(), np.zeros((6, 6))
@@ -449,8 +496,8 @@ def test_planar_pose_batch_matches_oracle(gpu_lib, oracle):
             r = out[i]
             assert r.core.success == bool(s.success) and abs(r.core.iterations - s.iterations) <= 1
             assert abs(r.reprojection_error - rms.value) <= 1e-9
-            assert np.abs(helpers.pose6_of(r.pose) - p).max() <= 1e-8
-            assert np.abs(r.distortion - d).max() <= 1e-7
+            assert np.abs(helpers.pose6_of(r.pose) - p).max() <= 1e-9   # the north-star's bar (planarpose.cpp:39-57)
+            assert np.abs(r.distortion - d).max() <= 1e-9
             assert r.core.covariance is not None and np.abs(r.core.covariance - cov).max() <= 1e-6 * np.abs(cov).max()
 
 
@@ -575,8 +622,8 @@ def test_semidlt_gpu_matches_oracle(gpu_lib, oracle, case):
     assert sta == 0 and stb == 0
     assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and abs(sa.iterations - sb.iterations) <= 2
     assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost)
-    assert np.abs(ka - kb).max() <= 1e-7 * np.abs(ka).max() and np.abs(pa - pb).max() <= 1e-8
-    assert np.abs(da - db).max() <= 1e-7 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-8
+    assert np.abs(ka - kb).max() <= 1e-9 * np.abs(ka).max() and np.abs(pa - pb).max() <= 1e-9   # the north-star's bar
+    assert np.abs(da - db).max() <= 1e-9 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-9
     if case["noise"] > 0:
         dg = np.sqrt(np.abs(np.diag(ca)))
         nz = dg > 0
@@ -789,7 +836,7 @@ def test_full_size_c3_properties(gpu_lib, lm_mode):
             assert xs["allreduce_calls"] == 1 + s.iterations + xs["speculation_misses"] + xs["rejected_steps"] + xs[
                 "line_search_evaluations"] + (s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"])
         cs = h.covariance_shared(o)
-        cs_err = gpu_lib.cba_last_error().decode() if cs is None else ""
+        assert cs is not None, gpu_lib.cba_last_error().decode()
         # the same solve again from the same start on the same handle: bitwise identical end state
         h.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
         s2 = h.solve(o)
@@ -797,16 +844,16 @@ def test_full_size_c3_properties(gpu_lib, lm_mode):
         assert all(np.array_equal(a, b) for a, b in zip(first, (sc.flat.intr, sc.flat.cam_pose, sc.flat.view_pose)))
     err = np.abs(sc.flat.intr - sc.gt_intr)
     assert err[:, :4].max() < 0.1  # fx, fy, cx, cy: 2e7 observations per camera at 0.2 px
-    assert err[:, 5].max() < 2e-3 and err[:, 8:10].max() < 1e-4  # k1 (strongly correlated with k2, k3 on this field of view), p1, p2
-    if cs is None:
-        # ceres::Covariance (SPARSE_QR) calls a column dependent when its R diagonal is below SuiteSparseQR's default tolerance
-        # 20 (m + n) eps max|J_j|, which grows with the row count: at m = 3.2e8 rows it is ~20 (in pixels per unit parameter) and
-        # the k3 pivot of a 0.8 m board at 2 m lies below it - the reference would return no covariance for this problem either
-        assert "rank deficient" in cs_err, cs_err
-    else:
-        sig = np.sqrt(np.diag(cs))[:err.size]
-        act = sig > 0
-        assert (err.reshape(-1)[act] <= 6.0 * sig[act]).all(), (err.reshape(-1)[act] / sig[act]).max()
+    # every intrinsic within 6 sigma of the engine's own shared-block covariance.  cba_reproj_covariance_shared tests the reciprocal
+    # condition number of the reduced system (1e-14, Ceres' own threshold) instead of a row-count-dependent QR tolerance, so it
+    # answers at this size.  The matrix is (J^T W J)^-1 as the reference's four main stages return it (unscaled, ceresutils.h:117-123
+    # scales only planar pose / homography / semi-DLT); with 0.2 px noise and the per-BLOCK Huber weight w ~ delta / |r_block| ~ 0.05
+    # of a 10 000-residual block its sigma over-states the estimator's standard deviation (0.2 px sqrt(w) ~ 0.045 of it): the
+    # check is conservative by that factor, and still far tighter than the absolute bounds below
+    sig = np.sqrt(np.diag(cs))[:err.size]
+    act = sig > 0
+    assert act.sum() >= 8 * 9 and (err.reshape(-1)[act] <= 6.0 * sig[act]).all(), (err.reshape(-1)[act] / sig[act]).max()
+    assert err[:, 5].max() < 2e-3 and err[:, 8:10].max() < 1e-4  # (absolute: k1 is strongly correlated with k2, k3 on this field of view)
 
 
 def test_exact_c1_shape_against_the_oracle(gpu_lib, oracle):

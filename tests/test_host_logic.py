@@ -159,12 +159,13 @@ LM_CASES = [
     ("intr", 0, {}, {}, 1e-9), ("intr", 0, dict(noise_px=0.2), {}, 1e-9), ("intr", 0, {}, dict(optimize_skew=1), 5e-9),
     ("intr", 1, dict(noise_px=0.2), {}, 1e-6),
     ("ext", 0, {}, {}, 1e-9), ("ext", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
-    ("ext", 0, dict(noise_px=0.2), dict(optimize_extrinsics=0), 1e-9), ("ext", 1, {}, dict(optimize_intrinsics=0), 1e-6),
+    ("ext", 0, dict(noise_px=0.2), dict(optimize_extrinsics=0), 1e-9), ("ext", 1, {}, dict(optimize_intrinsics=0), 1e-9),
+    ("ext", 1, {}, {}, 1e-9), ("ext", 1, dict(noise_px=0.2), {}, 1e-9),
     ("bundle", 0, {}, dict(optimize_intrinsics=1), 1e-9), ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, huber_delta=-1.0), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=0, optimize_target_pose=0), 1e-9),
     ("bundle", 0, dict(noise_px=0.2), dict(optimize_intrinsics=1, optimize_extrinsics=0), 1e-9),
-    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-6),
+    ("bundle", 1, {}, dict(optimize_intrinsics=1), 1e-9),
 ]
 
 
@@ -237,6 +238,18 @@ def test_scheimpflug_well_conditioned_scene_meets_the_1e9_bar(oracle, hostmath, 
     assert helpers.weak_direction_report(oracle, a.flat, b.flat)["kappa"] < 1e8  # an order or more below the narrow scenes
 
 
+@pytest.mark.parametrize("seed", [3, 5, 7])
+def test_scheimpflug_bundle_chain_meets_the_1e9_bar_with_noise(oracle, hostmath, seed):
+    """Scheimpflug on the two-pose BUNDLE chain, noisy, at 1e-9 on a scene that determines the sensor tilt (synth.scene_bundle_wide)."""
+    a, b = synth.scene_bundle_wide(seed=seed), synth.scene_bundle_wide(seed=seed)
+    o = options(epsilon=1e-12, optimize_intrinsics=1)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sa.success and sb.success and sb.iterations == sa.iterations
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-12 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-9
+
+
 @pytest.mark.parametrize("seed", [7, 11, 13])
 def test_scheimpflug_parity_gap_lies_in_the_flat_valley(oracle, hostmath, seed):
     """On the reference's test geometry (8 x 11 board of 0.2 m, mild tilts, one distance) the Scheimpflug tilt / principal point /
@@ -255,6 +268,30 @@ def test_scheimpflug_parity_gap_lies_in_the_flat_valley(oracle, hostmath, seed):
     assert helpers.param_diff(a.flat, b.flat) <= 1e-7
     if helpers.param_diff(a.flat, b.flat) > 1e-12:
         assert rep["weak3_share"] > 0.95 and rep["rayleigh_over_lmin"] < 100.0, rep
+
+
+@pytest.mark.parametrize("rec", [
+    dict(kind="intr", model=1, seed=4976, noise=0.5, okw=dict(huber_delta=0.3, optimize_skew=0), nv=7, nc=2, grid=(7, 11)),
+    dict(kind="intr", model=0, seed=705088, noise=0.1, okw=dict(huber_delta=3.0, optimize_skew=1), nv=6, nc=2, grid=(5, 5)),
+    dict(kind="bundle", model=1, seed=32942, noise=0.1, okw=dict(huber_delta=-1.0, optimize_skew=0, optimize_intrinsics=1, optimize_extrinsics=1,
+                                                                  optimize_target_pose=0), nv=8, nc=3, grid=(4, 9)),
+], ids=lambda r: f"{r['kind']}-{r['seed']}")
+def test_pinned_fuzz_disagreements_are_conditioning_not_arithmetic(oracle, hostmath, rec):
+    """The worst cases of the round-2 random sweeps (tools/fuzz_gpu.py), pinned: two correct solvers end 1e-6 .. 1e-3 apart in
+    parameters.  Not accepted on faith: the gap must be benign by helpers.gap_is_benign - same termination, >= 95 % of the scaled
+    difference in the three weakest eigen-directions of a Hessian with condition number > 1e6, nothing constant moved, and a cost
+    difference no larger than twice what the displacement predicts.  (GPU tier: the same test against the HIP engine.)"""
+    rows, cols = rec["grid"]
+    mk = {"intr": lambda: synth.scene_intrinsics(rec["nv"], rows=rows, cols=cols, spacing=0.08, model=rec["model"], noise_px=rec["noise"], seed=rec["seed"]),
+          "bundle": lambda: synth.scene_bundle(rec["nv"] + 4, rec["nc"], rows=rows, cols=cols, spacing=0.04, model=rec["model"], noise_px=rec["noise"], seed=rec["seed"])}[rec["kind"]]
+    a, b = mk(), mk()
+    o = options(epsilon=1e-12, **rec["okw"])
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    sb = hm_solve(hostmath, b.flat, o)
+    assert sa.termination == sb.termination
+    if helpers.param_diff(a.flat, b.flat) > 1e-9:
+        rep = helpers.solution_gap_report(oracle, hostmath, a.flat, b.flat, o)
+        assert helpers.gap_is_benign(rep, sa.final_cost, sb.final_cost), (helpers.param_diff(a.flat, b.flat), rep)
 
 
 @pytest.mark.parametrize("kind,model,seed", [("intr", 0, 7), ("ext", 0, 9), ("intr", 0, 19), ("ext", 0, 23), ("intr", 0, 4)])
@@ -475,7 +512,7 @@ def test_vp_per_view_lm_matches_oracle_and_reference_kat(oracle, hostmath, nr, d
         res[name] = (p, s, d, rms.value, cov)
     (pa, sa, da, ra, ca), (pb, sb, db, rb, cb) = res["oracle"], res["product"]
     assert sa.termination == sb.termination and abs(sa.iterations - sb.iterations) <= 1
-    assert np.abs(pa - pb).max() <= 1e-9 and np.abs(da - db).max() <= 1e-8 and abs(ra - rb) <= 1e-9
+    assert np.abs(pa - pb).max() <= 1e-9 and np.abs(da - db).max() <= 1e-9 and abs(ra - rb) <= 1e-9
     if noise > 0:  # (noise-free: ssr is rounding noise ~1e-25, so the ssr/dof-scaled covariance is too)
         assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
     if noise == 0.0:
@@ -615,9 +652,9 @@ def test_semidlt_lm_matches_oracle(oracle, hostmath, case):
     (_, ka, pa, sa, da, va, ca), (_, kb, pb, sb, db, vb, cb) = res["oracle"], res["product"]
     assert sa.termination == sb.termination == capi.TERM_CONVERGENCE and abs(sa.iterations - sb.iterations) <= 2
     assert abs(sa.final_cost - sb.final_cost) <= 1e-9 * max(1.0, sa.final_cost)
-    assert np.abs(ka - kb).max() <= 1e-7 * np.abs(ka).max()
-    assert np.abs(pa - pb).max() <= 1e-8
-    assert np.abs(da - db).max() <= 1e-7 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-8
+    assert np.abs(ka - kb).max() <= 1e-9 * np.abs(ka).max()   # the north-star's bar (intrinsicsemidltresidual.h:19-73)
+    assert np.abs(pa - pb).max() <= 1e-9
+    assert np.abs(da - db).max() <= 1e-9 * max(1.0, np.abs(da).max()) and np.abs(va - vb).max() <= 1e-9
     if case["noise"] > 0:
         assert np.any(ca) and np.any(cb)
         dg = np.sqrt(np.abs(np.diag(ca)))

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP engine against the CPU oracle: random chain / camera model / sizes / noise / stage switches /
-loss, LM to epsilon = 1e-12, compared on termination, iterations, cost and parameters.  Not part of the test suite (it is a
-search for disagreements, run with spare GPU time); prints one JSON summary line.  usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
+loss, LM to epsilon = 1e-12, compared on termination, iterations, cost and parameters.  Every case that misses the bar is
+CLASSIFIED (tests/helpers.py solution_gap_report / gap_is_benign): it is benign only if the two solvers terminated the same way,
+nearly all (>= 95 %) of the scaled parameter difference lies in the three weakest eigen-directions of an ill-conditioned
+Hessian, nothing moved that Ceres holds constant, and the costs differ by no more than that displacement explains.  Anything
+else is an UNEXPLAINED disagreement: the sweep prints it and exits 1.  Not part of the test suite (a search, run with spare GPU
+time; the cases it found are pinned in tests/test_gpu_parity.py); prints one JSON summary line.
+usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +16,8 @@ from tests import helpers
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 orc = helpers.load_oracle()
-worst, bad, t0 = 0.0, [], time.time()
+hm = helpers.load_hostmath()
+worst, bad, unexplained, t0 = 0.0, [], [], time.time()
 for i in range(n_cases):
     kind = ["intr", "ext", "bundle"][int(rng.integers(0, 3))]
     model = int(rng.integers(0, 2))
@@ -40,7 +46,14 @@ for i in range(n_cases):
     ok = sa.termination == sb.termination and abs(sa.iterations - sb.iterations) <= 2 and pd <= tol and \
         abs(sa.final_cost - sb.final_cost) <= 1e-8 * max(1.0, sa.final_cost) + 1e-14
     if not ok:
+        rep = helpers.solution_gap_report(orc, hm, a.flat, b.flat, o)
+        rec["gap"] = {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in rep.items()}
+        rec["benign"] = bool(sa.termination == sb.termination and helpers.gap_is_benign(rep, sa.final_cost, sb.final_cost))
         bad.append(rec)
+        if not rec["benign"]:
+            unexplained.append(rec)
     if model == 0 and not okw.get("optimize_skew"):
         worst = max(worst, pd)
-print(json.dumps(dict(cases=n_cases, disagreements=len(bad), worst_param_diff_pinhole_noskew=worst, seconds=time.time() - t0, bad=bad[:10])))
+print(json.dumps(dict(cases=n_cases, above_the_bar=len(bad), benign=len(bad) - len(unexplained), unexplained=len(unexplained),
+                      worst_param_diff_pinhole_noskew=worst, seconds=time.time() - t0, unexplained_cases=unexplained[:10], benign_cases=bad[:10])))
+sys.exit(1 if unexplained else 0)

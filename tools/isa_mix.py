@@ -41,6 +41,24 @@ def hist(sub):
 
 print(f"kernel: {body[0][:120]}")
 print(f"instructions: {len(insts)}, loops (size, start, end): {loops[:4]}")
+# A shared-rows kernel (kernels_modeb.hip) holds one body per wavefront of the workgroup ("part"), each with its own loop over the
+# groups of the tile; every such loop contains the workgroup barrier.  One pass of ALL of them handles NP chunks of 64 observations,
+# so the per-observation figures are the sums over the parts' loops divided by NP.
+bar_loops = sorted({(a, b) for _, a, b in loops if any(mn == "s_barrier" for _, mn, _ in insts[a:b + 1])})
+part_loops = [(a, b) for a, b in bar_loops if not any((a2 < a <= b2) or (a2 == a and b2 > b) for a2, b2 in bar_loops)]  # outermost
+if len(part_loops) > 1:
+    NP = len(part_loops)
+    tot = collections.Counter()
+    for a, b in part_loops:
+        tot.update(mn for _, mn, _ in insts[a:b + 1])
+    fma = sum(v for k, v in tot.items() if k.split("_e")[0] in ("v_fma_f64", "v_fmac_f64"))
+    muladd = sum(v for k, v in tot.items() if k.split("_e")[0] in ("v_mul_f64", "v_add_f64"))
+    valu = sum(v for k, v in tot.items() if k.startswith("v_"))
+    lds = sum(v for k, v in tot.items() if k.startswith("ds_"))
+    print(f"-- {NP} per-part group loops found (sizes {[b - a + 1 for a, b in part_loops]}; a part whose loop the assembler laid out without a "
+          f"backward branch of its own is not found: the mean stands for it): per observation = mean over the parts: "
+          f"{valu / NP:.1f} VALU, {lds / NP:.1f} LDS, fp64 FMA {fma / NP:.1f}, fp64 mul/add {muladd / NP:.1f}, "
+          f"FLOP (FMA=2, mul/add=1) {(2 * fma + muladd) / NP:.1f}")
 for name, sub in (("hottest loop", insts[loops[0][1]:loops[0][2] + 1] if loops else []), ("whole kernel", insts)):
     h, f64, fma, muladd, valu = hist(sub)
     print(f"-- {name}: {len(sub)} instructions, {valu} VALU, fp64 FMA {fma}, fp64 mul/add {muladd}, FLOP (FMA=2, mul/add=1) {2 * fma + muladd}")

@@ -7,7 +7,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
-extra = ["-fno-slp-vectorize"] if src.startswith("kernels_reproj") else []
+extra = ["-fno-slp-vectorize"] if src.startswith("kernels_") else []
+extra += [a for a in sys.argv[3:] if a.startswith("-D")]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm",
        "-unroll-threshold=1000000", *extra, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
 if src.endswith(".cpp"):
