@@ -1,4 +1,6 @@
-set -e
+set -u
 mkdir -p gpurun_out
-echo "== c2 direct parts"; for dp in 2 3 4; do CBA_MODEB_DPARTS=$dp EXP_TAG="dparts$dp" python tools/exp_modeb.py c2 c5 2>&1 | grep -v amdgpu; done
-echo "== c3q moment variants"; for v in 4 36 3 5; do CBA_MODEB_VARIANT=$v EXP_TAG="variant$v" python tools/exp_modeb.py c3q c4 2>&1 | grep -v amdgpu; done
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r03_t5.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/r03_t5.log
+timeout -k 10 300 python tools/fuzz_gpu.py 3000 3031 > gpurun_out/r03_fuzz_auto.json 2> gpurun_out/r03_fuzz1.err; echo "fuzz rc=$?"; head -c 500 gpurun_out/r03_fuzz_auto.json
+CBA_LM_RESIDENT=0 timeout -k 10 300 python tools/fuzz_gpu.py 3000 3032 > gpurun_out/r03_fuzz_host_driven.json 2> gpurun_out/r03_fuzz2.err; echo "fuzz rc=$?"; head -c 500 gpurun_out/r03_fuzz_host_driven.json
+timeout -k 10 300 python tools/fuzz_small.py > gpurun_out/r03_fuzz_small.json 2> gpurun_out/r03_fuzz3.err; echo "fuzz small rc=$?"; head -c 600 gpurun_out/r03_fuzz_small.json
