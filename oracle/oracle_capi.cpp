@@ -624,19 +624,18 @@ int orc_semidlt_solve(int n_views, const int64_t* off, const double* X, const do
         std::vector<int> fr;
         for (int a = 0; a < m; ++a) if (!fixed[a]) fr.push_back(a);
         const int nf = static_cast<int>(fr.size());
-        if (nf > 0) {
-            std::vector<double> Nf(static_cast<size_t>(nf) * nf, 0.0), bf(nf, 0.0);
+        if (nf > 0) {  // distortion.h:333-356: the free columns, the right-hand side minus the fixed columns' share, thin SVD solve
+            std::vector<double> Af(static_cast<size_t>(2 * N) * nf), badj(2 * N), af(nf);
             for (int rw = 0; rw < 2 * N; ++rw) {
-                double badj = b[rw];
-                for (int a = 0; a < m; ++a) if (fixed[a]) badj -= A[static_cast<size_t>(rw) * m + a] * alpha[a];
-                for (int i = 0; i < nf; ++i) {
-                    bf[i] += A[static_cast<size_t>(rw) * m + fr[i]] * badj;
-                    for (int j = 0; j < nf; ++j) Nf[static_cast<size_t>(i) * nf + j] += A[static_cast<size_t>(rw) * m + fr[i]] * A[static_cast<size_t>(rw) * m + fr[j]];
-                }
+                badj[rw] = b[rw];
+                for (int a = 0; a < m; ++a) if (fixed[a]) badj[rw] -= A[static_cast<size_t>(rw) * m + a] * alpha[a];
+                for (int i = 0; i < nf; ++i) Af[static_cast<size_t>(rw) * nf + i] = A[static_cast<size_t>(rw) * m + fr[i]];
             }
-            if (!cholesky_inplace(Nf, nf)) throw std::runtime_error("Failed to compute distortion parameters");
-            cholesky_solve(Nf, nf, bf);
-            for (int i = 0; i < nf; ++i) alpha[fr[i]] = bf[i];
+            lstsq_svd<double>(Af, 2 * N, nf, badj, af.data());
+            for (int i = 0; i < nf; ++i) {
+                if (!std::isfinite(af[i])) throw std::runtime_error("Failed to compute distortion parameters");
+                alpha[fr[i]] = af[i];
+            }
         }
         double ssr = 0;
         {

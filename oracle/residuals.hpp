@@ -129,12 +129,73 @@ inline void angle_axis_rotate_point(const T* aa, const T* pt, T* out) {
     }
 }
 
+// argmin |A x - b| the way the reference computes it (models/distortion.h:290-294): thin SVD of the design matrix and
+// x = V diag(1 / sigma_j) U^T b over the singular values above Eigen's default rank threshold (SVDBase::threshold():
+// min(rows, cols) * epsilon, relative to the largest) - the MINIMUM-NORM solution when A is rank deficient (near-collinear
+// points), where normal equations would divide by a rounding-noise pivot.  The SVD is a one-sided Jacobi (Hestenes) iteration on
+// the columns of A - every operation on T, so the derivative parts of Jets ride through the rotations exactly as they ride
+// through Eigen::JacobiSVD in the reference (the rotation pattern is decided by the scalar parts).  Eigen is a third-party
+// dependency absent from /root/reference: restated, like the rest of this directory.
+// A is rows x m row-major (destroyed: it leaves as U Sigma), m <= 8.
+template <typename T>
+void lstsq_svd(std::vector<T>& A, int rows, int m, const std::vector<T>& b, T* x) {
+    std::vector<T> V(static_cast<size_t>(m) * m, T(0.0));
+    for (int j = 0; j < m; ++j) V[j * m + j] = T(1.0);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                T al(0.0), be(0.0), ga(0.0);
+                for (int r = 0; r < rows; ++r) {
+                    const T& wp = A[static_cast<size_t>(r) * m + p];
+                    const T& wq = A[static_cast<size_t>(r) * m + q];
+                    al = al + wp * wp; be = be + wq * wq; ga = ga + wp * wq;
+                }
+                const double a0 = scalar_of(al), b0 = scalar_of(be), g0 = scalar_of(ga);
+                if (a0 == 0.0 || b0 == 0.0) continue;
+                const double rel = std::fabs(g0) / std::sqrt(a0 * b0);
+                off = std::max(off, rel);
+                if (rel <= 1e-16) continue;
+                const T zeta = (be - al) / (T(2.0) * ga);
+                const T t = (scalar_of(zeta) >= 0.0 ? T(1.0) : T(-1.0)) / (abs(zeta) + sqrt(T(1.0) + zeta * zeta));
+                const T c = T(1.0) / sqrt(T(1.0) + t * t), sn = c * t;
+                for (int r = 0; r < rows; ++r) {
+                    const T wp = A[static_cast<size_t>(r) * m + p], wq = A[static_cast<size_t>(r) * m + q];
+                    A[static_cast<size_t>(r) * m + p] = c * wp - sn * wq;
+                    A[static_cast<size_t>(r) * m + q] = sn * wp + c * wq;
+                }
+                for (int r = 0; r < m; ++r) {
+                    const T vp = V[r * m + p], vq = V[r * m + q];
+                    V[r * m + p] = c * vp - sn * vq;
+                    V[r * m + q] = sn * vp + c * vq;
+                }
+            }
+        if (off <= 1e-15) break;
+    }
+    std::vector<T> s2(m, T(0.0)), wb(m, T(0.0));
+    double smax2 = 0.0;
+    for (int j = 0; j < m; ++j) {
+        for (int r = 0; r < rows; ++r) {
+            s2[j] = s2[j] + A[static_cast<size_t>(r) * m + j] * A[static_cast<size_t>(r) * m + j];
+            wb[j] = wb[j] + A[static_cast<size_t>(r) * m + j] * b[r];
+        }
+        smax2 = std::max(smax2, scalar_of(s2[j]));
+    }
+    const double thr = static_cast<double>(std::min(rows, m)) * 2.220446049250313e-16;
+    for (int i = 0; i < m; ++i) x[i] = T(0.0);
+    for (int j = 0; j < m; ++j) {
+        if (!(std::sqrt(scalar_of(s2[j])) > thr * std::sqrt(smax2))) continue;  // below the rank threshold: left out (minimum norm)
+        const T coef = wb[j] / s2[j];
+        for (int i = 0; i < m; ++i) x[i] = x[i] + V[i * m + j] * coef;
+    }
+}
+
 // PlanarPoseVPResidual::operator(), src/estimation/optim/planarpose.cpp:39-57:
 //   to_observation (observationutils.h:97-113) -> fit_distortion_full (models/distortion.h:229-295)
 //   -> residual = A alpha - b with alpha = argmin |A alpha - b|.
-// The reference solves the least squares with a thin JacobiSVD on Jets (distortion.h:290-294); for a full
-// column rank A the minimiser is unique, and it is computed here from the normal equations (Cholesky on
-// Jets), which differentiates to the same Golub-Pereyra derivative.
+// The reference solves the least squares with a thin JacobiSVD on Jets (distortion.h:290-294): so does the oracle (lstsq_svd
+// above), including the minimum-norm behaviour on rank-deficient designs.  (The product uses normal equations and an analytic
+// Golub-Pereyra derivative: the same minimiser at full column rank, compared in tests/.)
 struct PlanarPoseVPBlock final : ResidualBlock {
     ViewData view;
     double K[5];  // fx fy cx cy skew
@@ -172,33 +233,11 @@ struct PlanarPoseVPBlock final : ResidualBlock {
             b[2 * i] = T(view.u[i]) - (fx * x + skew * y + cx);
             b[2 * i + 1] = T(view.v[i]) - (fy * y + cy);
         }
-        // normal equations + Cholesky
-        std::vector<T> M(static_cast<size_t>(m) * m, T(0.0)), rhs(m, T(0.0)), L(static_cast<size_t>(m) * m, T(0.0)), al(m);
-        for (int row = 0; row < 2 * N; ++row)
-            for (int a = 0; a < m; ++a) {
-                rhs[a] = rhs[a] + A[static_cast<size_t>(row) * m + a] * b[row];
-                for (int c = 0; c <= a; ++c) M[a * m + c] = M[a * m + c] + A[static_cast<size_t>(row) * m + a] * A[static_cast<size_t>(row) * m + c];
-            }
-        for (int j = 0; j < m; ++j) {
-            T d = M[j * m + j];
-            for (int k = 0; k < j; ++k) d = d - L[j * m + k] * L[j * m + k];
-            d = sqrt(d);
-            L[j * m + j] = d;
-            for (int i = j + 1; i < m; ++i) {
-                T sacc = M[i * m + j];
-                for (int k = 0; k < j; ++k) sacc = sacc - L[i * m + k] * L[j * m + k];
-                L[i * m + j] = sacc / d;
-            }
-        }
-        for (int i = 0; i < m; ++i) {
-            T sacc = rhs[i];
-            for (int k = 0; k < i; ++k) sacc = sacc - L[i * m + k] * al[k];
-            al[i] = sacc / L[i * m + i];
-        }
-        for (int i = m - 1; i >= 0; --i) {
-            T sacc = al[i];
-            for (int k = i + 1; k < m; ++k) sacc = sacc - L[k * m + i] * al[k];
-            al[i] = sacc / L[i * m + i];
+        // least squares by SVD (distortion.h:290-294); A is needed again for the residual: the SVD works on a copy
+        std::vector<T> al(m);
+        {
+            std::vector<T> W = A;
+            lstsq_svd<T>(W, 2 * N, m, b, al.data());
         }
         for (int row = 0; row < 2 * N; ++row) {
             T sacc = -b[row];
@@ -226,7 +265,7 @@ struct PlanarPoseVPBlock final : ResidualBlock {
 // [intr(5) | quat_0(4) tran_0(3) | quat_1 tran_1 | ...]; every view's points go through
 // planar_observables_to_observables (observationutils.h:78-95: point = c_se3_t * (X, Y, 0), xn = x/z, yn = y/z with the
 // rotation from quat_array_to_rotmat, no normalisation), then ONE fit_distortion_full over all observations
-// (distortion.h:229-295) and residual = A alpha - b.  Least squares by normal equations on Jets, as in PlanarPoseVPBlock.
+// (distortion.h:229-295) and residual = A alpha - b.  Least squares by SVD on Jets (lstsq_svd), as the reference does.
 // Jets are NJ = 5 + 7 * VMAX wide: the oracle handles up to VMAX views (enough for the tests).
 struct CalibVPBlock final : ResidualBlock {
     static constexpr int VMAX = 6, NJ = 5 + 7 * VMAX;
@@ -271,32 +310,10 @@ struct CalibVPBlock final : ResidualBlock {
                 b[row + 1] = T(view.v[i]) - (fy * y + cy);
             }
         }
-        std::vector<T> M(static_cast<size_t>(m) * m, T(0.0)), rhs(m, T(0.0)), L(static_cast<size_t>(m) * m, T(0.0)), al(m);
-        for (int rw = 0; rw < 2 * N; ++rw)
-            for (int a = 0; a < m; ++a) {
-                rhs[a] = rhs[a] + A[static_cast<size_t>(rw) * m + a] * b[rw];
-                for (int c = 0; c <= a; ++c) M[a * m + c] = M[a * m + c] + A[static_cast<size_t>(rw) * m + a] * A[static_cast<size_t>(rw) * m + c];
-            }
-        for (int j = 0; j < m; ++j) {
-            T d = M[j * m + j];
-            for (int k = 0; k < j; ++k) d = d - L[j * m + k] * L[j * m + k];
-            d = sqrt(d);
-            L[j * m + j] = d;
-            for (int i = j + 1; i < m; ++i) {
-                T sacc = M[i * m + j];
-                for (int k = 0; k < j; ++k) sacc = sacc - L[i * m + k] * L[j * m + k];
-                L[i * m + j] = sacc / d;
-            }
-        }
-        for (int i = 0; i < m; ++i) {
-            T sacc = rhs[i];
-            for (int k = 0; k < i; ++k) sacc = sacc - L[i * m + k] * al[k];
-            al[i] = sacc / L[i * m + i];
-        }
-        for (int i = m - 1; i >= 0; --i) {
-            T sacc = al[i];
-            for (int k = i + 1; k < m; ++k) sacc = sacc - L[k * m + i] * al[k];
-            al[i] = sacc / L[i * m + i];
+        std::vector<T> al(m);
+        {
+            std::vector<T> W = A;
+            lstsq_svd<T>(W, 2 * N, m, b, al.data());  // distortion.h:290-294
         }
         for (int rw = 0; rw < 2 * N; ++rw) {
             T sacc = -b[rw];

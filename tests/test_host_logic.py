@@ -533,6 +533,54 @@ def test_vp_too_few_points_is_failure_not_exception(hostmath):
     assert s.termination == capi.TERM_FAILURE and not s.success
 
 
+def _planar_both(oracle, hostmath, view, init, nr, eps=1e-12):
+    X, Y, u, v = (np.ascontiguousarray(view[:, k]) for k in range(4))
+    o = options(epsilon=eps)
+    out = {}
+    for name, fn in (("oracle", oracle.orc_planar_pose_solve), ("product", hostmath.hm_planar_pose_solve)):
+        p, s, d, rms = helpers.pose6_of(init), CbaSummary(), np.zeros(nr + 2), C.c_double()
+        st = fn(len(view), dptr(X), dptr(Y), dptr(u), dptr(v), dptr(helpers.PLANAR_K), nr, dptr(p), C.byref(o), C.byref(s), dptr(d), C.byref(rms), dptr(None))
+        out[name] = (st, p, s, d, rms.value)
+    return out
+
+
+def test_vp_edge_cases_follow_the_reference(oracle, hostmath):
+    """The corners of fit_distortion_full (include/calib/models/distortion.h:229-295) that the round-2 oracle did not restate: the
+    reference solves the inner least squares with a thin JacobiSVD (:290-294) - the oracle now does too (oracle/residuals.hpp
+    lstsq_svd) - and guards only the observation count (:236-239).  The product keeps normal equations; these cases pin where
+    the two forms agree and what happens where they cannot."""
+    view, true, init = helpers.planar_pose_scene(distort=True, noise=0.2)
+    # exactly 8 observations: the smallest problem the reference accepts - both solve it, same minimiser
+    r = _planar_both(oracle, hostmath, view[[0, 5, 7, 14, 21, 28, 30, 35]], init, 0)
+    (sta, pa, sa, da, ra), (stb, pb, sb, db, rb) = r["oracle"], r["product"]
+    assert sta == 0 and stb == 0 and sa.success and sb.success
+    assert np.abs(pa - pb).max() <= 1e-9 and np.abs(da - db).max() <= 1e-9 and abs(ra - rb) <= 1e-9
+    # 7 observations: fit_distortion_full returns nullopt, the residual block reports failure (planarpose.cpp:51-53):
+    # the oracle refuses the block, the product reports FAILURE (no exception)
+    r = _planar_both(oracle, hostmath, view[:7], init, 0)
+    assert r["oracle"][0] != 0 and r["product"][0] == 0 and r["product"][2].termination == capi.TERM_FAILURE
+    # three radial coefficients from ONE small view (3 x 3 points, 18 rows for 5 unknowns, rho ~ 1e-3: the radial columns are nearly
+    # parallel).  Full column rank still: SVD and normal equations reach the same residual; the coefficients themselves are
+    # only determined to cond * eps, so they are compared through what they predict (the RMS), and the poses to 1e-6
+    small = view[[0, 2, 5, 12, 14, 17, 30, 32, 35]]
+    r = _planar_both(oracle, hostmath, small, init, 3)
+    (sta, pa, sa, da, ra), (stb, pb, sb, db, rb) = r["oracle"], r["product"]
+    assert sta == 0 and stb == 0 and sa.termination == sb.termination
+    assert abs(ra - rb) <= 1e-7 and np.abs(pa - pb).max() <= 1e-6
+    # collinear target points (a 1 x 9 line): the pose is not observable about the line and the design loses rank.  The reference
+    # goes on with the SVD's minimum-norm coefficients; neither restatement may throw or return non-finite numbers, and whatever
+    # each reports as converged must explain the data equally well
+    line = np.array([[x, 0.0] for x in np.linspace(-0.4, 0.4, 9)])
+    cam = np.concatenate([helpers.PLANAR_K, [0, 0, 0, 0.1, 0.0]])
+    lv = synth.render_view(cam, true, line, cull=False)
+    r = _planar_both(oracle, hostmath, lv, init, 1, eps=1e-9)
+    (sta, pa, sa, da, ra), (stb, pb, sb, db, rb) = r["oracle"], r["product"]
+    assert sta == 0 and stb == 0
+    assert np.isfinite(pa).all() and np.isfinite(pb).all() and np.isfinite(ra) and np.isfinite(rb)
+    if sa.success and sb.success:
+        assert abs(ra - rb) <= 1e-3  # (both fit the line's 18 residuals essentially exactly; which pose of the unobservable family differs)
+
+
 # ---- homography: the product's per-view solver (hom_math.hpp + small_lm.hpp) on the single-thread group ------
 def test_homography_normal_equations_match_oracle_jets(oracle, hostmath):
     """Per-correspondence Huber weights: H = sum w_i J_i^T J_i, g = sum w_i J_i^T r_i, cost = 1/2 sum rho(|r_i|^2)."""
