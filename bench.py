@@ -67,7 +67,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from calibration_amd import capi, optim, synth
+    from calibration_amd import capi, optim
+    from tests import synth
 
     lib = capi.load_library()
     if lib.cba_device_count() <= 0:

@@ -1279,7 +1279,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
         warm_reproj_kernels();
     }
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
-    if (const char* env = std::getenv("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
     if (const char* env = std::getenv("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);

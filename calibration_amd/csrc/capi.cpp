@@ -198,7 +198,7 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     e.n_obs = st.n_obs;
     e.ld = (pad + 255) & ~int64_t(255);
     if (e.ld == 0) e.ld = 256;
-    if (const char* lp = getenv("CBA_LD_MOD")) {
+    if (const char* lp = cba_exp_env("CBA_LD_MOD")) {
         // experiment: force (ld * 8) mod 2 MiB == CBA_LD_MOD bytes (multiple of 256)
         const int64_t period = (2 << 20) / 8, want = atoll(lp) / 8;
         int64_t ld = (e.ld / period) * period + want;
@@ -350,8 +350,8 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     e.blk_acc.alloc(static_cast<size_t>(d.n_blocks) * e.NACC);
     if (d.chain != CBA_CHAIN_INTRINSIC) e.blk_mom.alloc(static_cast<size_t>(std::max(1, d.n_blocks)) * 256);
     if (const char* env = std::getenv("CBA_MODEB_MOMENTS")) e.modeb_moments = std::atoi(env);
-    if (const char* env = std::getenv("CBA_MODEB_SPLIT")) e.modeb_split = std::atoi(env);
-    if (const char* env = std::getenv("CBA_MODEB_SHARED")) e.modeb_shared = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_MODEB_SPLIT")) e.modeb_split = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_MODEB_SHARED")) e.modeb_shared = std::atoi(env);
     e.blk_s.alloc(d.n_blocks);
     e.scalar_out.alloc(8);
     e.cost_part.alloc(static_cast<size_t>(2 * ((d.n_blocks + 2047) / 2048 + 1)));  // allocated here: launch_cost may run inside a graph capture
@@ -554,7 +554,7 @@ cba_status cba_reproj_eval_timed(cba_reproj* h, int32_t warmup, int32_t iters, d
         // tuning knobs are re-read here so one handle (one set of buffers) can time every variant
         if (const char* ev = getenv("CBA_EVAL_VARIANT")) e.eval_variant = atoi(ev);
         if (const char* eb = getenv("CBA_EVAL_BLOCKED")) e.eval_blocked = atoi(eb);
-        if (const char* ea = getenv("CBA_EVAL_ABLATE")) e.eval_ablate = atoi(ea);
+        if (const char* ea = cba_exp_env("CBA_EVAL_ABLATE")) e.eval_ablate = atoi(ea);
         ensure_eval_buffers(e);
         launch_block_consts(e, 0);
         for (int i = 0; i < warmup; ++i) launch_eval(e);

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <exception>
 #include <stdexcept>
 #include <string>
@@ -37,6 +38,20 @@ struct HipError : std::runtime_error {
 struct NoDevice : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+
+// Environment switches.  The shipped library reads a short, documented list of run-time switches with std::getenv (DESIGN.md
+// section 9: every one of them selects between forms that give the same results).  Everything else that was ever tuned or ablated
+// through the environment - part counts, layouts, timing-only ablations whose results are WRONG - is an experiment knob: read
+// through cba_exp_env(), which answers only in a library built with -DCBA_EXPERIMENTS (make EXPERIMENTS=1; tools/exp.py uses such
+// a build).  In the shipped library a stray variable in a user's environment cannot change what a calibration computes.
+inline const char* cba_exp_env(const char* name) {
+#ifdef CBA_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 #define CBA_HIP(expr)                                                                                      \
     do {                                                                                                   \

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
 // ---- launchers ------------------------------------------------------------------------------------------------------------
 template <class FORM, int NBUF, typename T>
 static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
-    static const bool one_ok = !(std::getenv("CBA_MODEB_ONEGROUP") && std::atoi(std::getenv("CBA_MODEB_ONEGROUP")) == 0);
+    static const bool one_ok = !(cba_exp_env("CBA_MODEB_ONEGROUP") && std::atoi(cba_exp_env("CBA_MODEB_ONEGROUP")) == 0);
     if (NBUF == 1 && one_ok && e.max_tileB <= 64 * FORM::NPARTS)  // every tile is one group: the single-group kernel
         hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream,
                            e.gate, e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
@@ -195,8 +195,8 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
     // Scheimpflug 2: 0.303 / 3: 0.306 / 4: 0.265; moment form (C3 / 4), pinhole 2: 1.075 / 3: 0.939 / 4: 0.830 / 5: 1.415 (LDS-limited
     // occupancy) with the family-aligned split of MomSplitTable (round-robin entries: 1.002 / 0.955 / 0.907 / 1.618), double-buffered
     // rows 0.961 (no gain: the barrier that remains is the one that costs).
-    static const int dparts_env = std::getenv("CBA_MODEB_DPARTS") ? std::atoi(std::getenv("CBA_MODEB_DPARTS")) : 0;
-    static const int variant = std::getenv("CBA_MODEB_VARIANT") ? std::atoi(std::getenv("CBA_MODEB_VARIANT")) : 4;
+    static const int dparts_env = cba_exp_env("CBA_MODEB_DPARTS") ? std::atoi(cba_exp_env("CBA_MODEB_DPARTS")) : 0;
+    static const int variant = cba_exp_env("CBA_MODEB_VARIANT") ? std::atoi(cba_exp_env("CBA_MODEB_VARIANT")) : 4;
     const int dparts = dparts_env ? dparts_env : (e.model == CAM_SCHEIMPFLUG ? 4 : 2);
     if (e.chain == CH_INTRINSIC) {
         if (e.model == CAM_PINHOLE_BC) {
@@ -216,6 +216,7 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
             else if ((variant & 15) == 4) launch_both<MomentForm<CAM_PINHOLE_BC, 4, double>, MomentForm<CAM_PINHOLE_BC, 4, float>>(e, rows);
             else if ((variant & 15) == 5) launch_both<MomentForm<CAM_PINHOLE_BC, 5, double>, MomentForm<CAM_PINHOLE_BC, 5, float>>(e, rows);
             else if (variant & 16) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>, 2>(e, rows);
+#ifdef CBA_EXPERIMENTS
             else if (variant >= 32 && variant != 36 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
                 using F = MomentForm<CAM_PINHOLE_BC, 3, double>;
                 const dim3 g(static_cast<unsigned>(e.n_tilesB)), b(64 * 3);
@@ -223,7 +224,9 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
                                       e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.PI, rows)
                 if (variant == 33) CBA_ABL(1); else if (variant == 34) CBA_ABL(2); else CBA_ABL(3);
 #undef CBA_ABL
-            } else launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
+            }
+#endif
+            else launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
         } else {
             if ((variant & 15) == 5) launch_both<MomentForm<CAM_SCHEIMPFLUG, 5, double>, MomentForm<CAM_SCHEIMPFLUG, 5, float>>(e, rows);
             else if ((variant & 15) == 2) launch_both<MomentForm<CAM_SCHEIMPFLUG, 3, double>, MomentForm<CAM_SCHEIMPFLUG, 3, float>>(e, rows);

@@ -443,11 +443,14 @@ static void launch_eval_v(Engine& e) {
     const unsigned g = blocks_for(e.n_tilesA, 4 * ROWS);
 #define CBA_EVAL_ARGS dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p, intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, \
                       e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld
+#ifdef CBA_EXPERIMENTS  // timing-only ablations of k_eval (outputs are wrong): experiment builds only
     if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 1)
         hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), CBA_EVAL_ARGS);
     else if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 2)
         hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), CBA_EVAL_ARGS);
-    else if (e.eval_blocked)
+    else
+#endif
+    if (e.eval_blocked)
         hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), CBA_EVAL_ARGS);
     else
         hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), CBA_EVAL_ARGS);

@@ -26,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from calibration_amd import synth  # noqa: E402
+from tests import synth  # noqa: E402
 from calibration_amd.geometry import (axis_angle_to_R, inv, make_pose, pose_from_matrix, quat_to_rotmat)  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -91,7 +91,7 @@ def cstep(f, theta):
 
 
 def main():
-    from calibration_amd import synth
+    from tests import synth
     from calibration_amd.geometry import pose_from_matrix
 
     rng = np.random.default_rng(20261004)

@@ -275,7 +275,7 @@ PLANAR_K = np.array([1000.0, 1000.0, 500.0, 500.0, 0.0])
 def planar_pose_scene(distort=False, noise=0.0, seed=0):
     """create_synthetic_planar_data: 6x6 grid (i, j in -5..5 step 2) * 0.1 m, pose rot 0.1 rad about (1,1,1),
     t = (0.1, 0.2, 2.0); optional Brown-Conrady coeffs (0.1, 0) = [p1, p2] as in the reference test."""
-    from calibration_amd import synth
+    from tests import synth
     from calibration_amd.geometry import make_pose
 
     true = make_pose([0.1, 0.2, 2.0], [1, 1, 1], 0.1)
@@ -362,7 +362,7 @@ def is_approx(a, b, tol):
 def semidlt_scene(n_views=5, rows=6, cols=7, noise=0.0, seed=3, nr=2):
     """Views of a rows x cols grid through a pinhole + Brown-Conrady camera whose coefficients beyond num_radial are zero, so
     the variable-projection model is exact: returns (flat problem with perturbed K / poses, K_gt(5), alpha_gt(nr + 2))."""
-    from calibration_amd import synth
+    from tests import synth
 
     sc = synth.scene_intrinsics(n_views, rows=rows, cols=cols, spacing=0.08, noise_px=noise, seed=seed)
     cam = sc.gt_intr.reshape(-1).copy()
@@ -604,7 +604,7 @@ def gap_is_benign(rep: dict, cost_a: float, cost_b: float, iters=(0, 0), share=0
 def rough_start_scene(kind, model, seed):
     """A scene whose start point is far enough from the optimum (focal lengths 20 % short, no distortion, 0.5 px noise) that some
     trust-region steps fail the Armijo test: bounds-constrained problems then go through Ceres' projected line search."""
-    from calibration_amd import synth
+    from tests import synth
 
     sc = synth.scene_intrinsics(6, model=model, noise_px=0.5, seed=seed) if kind == "intr" else synth.scene_extrinsics(4, 2, model=model, noise_px=0.5, seed=seed)
     sc.flat.intr[:, 5:10] = 0.0

@@ -14,9 +14,9 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import capi
-from .geometry import inv, make_pose, pose_from_matrix, quat_to_rotmat
-from .optim import FlatProblem
+from calibration_amd import capi
+from calibration_amd.geometry import inv, make_pose, pose_from_matrix, quat_to_rotmat
+from calibration_amd.optim import FlatProblem
 
 GT_K = np.array([1000.0, 1005.0, 640.0, 360.0, 0.0])  # intrinsics_optimize_test.cpp:11-17
 GT_DIST = np.array([-0.12, 0.02, 0.0005, -0.0007, 0.001])  # bundle_test.cpp:165 [k1,k2,k3,p1,p2]

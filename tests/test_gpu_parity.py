@@ -18,7 +18,8 @@ import os
 import numpy as np
 import pytest
 
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 from tests import helpers
 from tests.helpers import options
 

@@ -15,7 +15,8 @@ import re
 import numpy as np
 import pytest
 
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 from calibration_amd.capi import CbaOptions, CbaSummary, dptr
 from calibration_amd.geometry import make_pose, pose_from_matrix, pose_to_matrix
 from tests import helpers

@@ -29,7 +29,7 @@ def _free_port():
 
 
 def _scene(kind):
-    from calibration_amd import synth
+    from tests import synth
 
     if kind == "intr":
         return synth.scene_intrinsics(11, spacing=0.08, noise_px=0.2)
@@ -47,7 +47,8 @@ def _worker(rank, world, port, kind, okw, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from calibration_amd import capi, synth
+    from calibration_amd import capi
+    from tests import synth
     from calibration_amd.capi import CbaSummary
     from tests import helpers
 
@@ -132,7 +133,8 @@ def _gpu_worker(rank, world, port, kind, okw, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from calibration_amd import optim, synth
+    from calibration_amd import optim
+    from tests import synth
     from tests import helpers
 
     flat = synth.shard_views(_scene(kind).flat, rank, world)
@@ -314,7 +316,7 @@ def _threaded_solve(hm, flats, okw):
 
 def _random_case(case):
     """(kind, world, okw, make) of random problem `case`: make() builds the scene afresh (same seed: identical data)."""
-    from calibration_amd import synth
+    from tests import synth
 
     rng = np.random.default_rng(1000 + case)
     kind = ["intr", "ext", "bundle"][case % 3]
@@ -352,7 +354,8 @@ def test_random_problems_over_in_process_ranks(hostmath, case):
     """The multi-rank protocol on random problems, including the rare paths: rough starts (line-search samples, rejected steps,
     radius misses, plain trials), more ranks than views (empty shards), loss on / off, intrinsics fixed / free.  Every rank must
     issue the same exchange sequence, end bit-identical in the replicated blocks and agree with the 1-rank solve."""
-    from calibration_amd import capi, synth
+    from calibration_amd import capi
+    from tests import synth
     from calibration_amd.capi import CbaSummary
     from tests import helpers
 
@@ -382,7 +385,8 @@ def test_random_problems_over_in_process_ranks_gpu(case):
     """The same random problems on the REAL engine: one handle per rank on GPU 0, each driven from its own thread, the packed
     all-reduce through the host-callback transport.  Same exchange sequence on every rank, replicated blocks bit-identical,
     1-rank GPU solve reproduced."""
-    from calibration_amd import optim, synth
+    from calibration_amd import optim
+    from tests import synth
     from tests import helpers
 
     _kind, world, okw, make = _random_case(case)

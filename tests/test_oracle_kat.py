@@ -13,7 +13,8 @@ import os
 import numpy as np
 import pytest
 
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 from calibration_amd.capi import CbaSummary, dptr
 from calibration_amd.geometry import pose_from_matrix, pose_to_matrix, rotation_angle
 from tests import helpers

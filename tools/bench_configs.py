@@ -6,7 +6,8 @@ import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 from calibration_amd.geometry import pose_from_matrix, pose_to_matrix, rotation_angle
 from tests import helpers
 

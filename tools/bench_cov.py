@@ -4,7 +4,8 @@ view counts.  One JSON line per size."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 
 for n_views, grid, full in ((100, 30, True), (1000, 30, True), (1000, 100, False), (4000, 30, False)):
     sc = synth.scene_intrinsics(n_views, rows=grid, cols=grid, spacing=0.8 / grid, noise_px=0.2)

@@ -11,7 +11,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from calibration_amd import optim, synth  # noqa: E402
+from calibration_amd import optim  # noqa: E402
+from tests import synth  # noqa: E402
 
 
 def main():

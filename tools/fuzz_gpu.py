@@ -13,7 +13,8 @@ usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from calibration_amd import optim, synth
+from calibration_amd import optim
+from tests import synth
 from tests import helpers
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150

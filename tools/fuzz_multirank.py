@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from calibration_amd import capi, optim, synth  # noqa: E402
+from calibration_amd import capi, optim  # noqa: E402
+from tests import synth  # noqa: E402
 from calibration_amd.capi import CbaSummary  # noqa: E402
 from tests import helpers  # noqa: E402
 from tests import test_multirank_gloo as T  # noqa: E402

@@ -4,7 +4,8 @@ usage: python tools/fuzz_small.py [n_cases] [seed]"""
 import ctypes as C, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from calibration_amd import capi, optim, synth
+from calibration_amd import capi, optim
+from tests import synth
 from calibration_amd.capi import CbaSummary, dptr
 from calibration_amd.geometry import pose_to_matrix
 from tests import helpers
