@@ -529,7 +529,27 @@ static void ensure_eval_buffers(Engine& e) {
         return;
     }
     if (!e.eval_blocked && e.r.n < static_cast<size_t>(2 * e.ld)) e.r.alloc(static_cast<size_t>(2 * e.ld));
-    const size_t jn = e.eval_blocked ? static_cast<size_t>(e.n_tilesA) * (2 + 2 * e.PL) * TILE_A : static_cast<size_t>(2 * e.PL) * e.ld;
+    const size_t tw = static_cast<size_t>(2 + 2 * e.PL) * TILE_A;
+    const size_t jn = e.eval_blocked ? static_cast<size_t>(e.n_tilesA) * tw : static_cast<size_t>(2 * e.PL) * e.ld;
+    // (measured at C3, 59 GB: 15 segments 11.12 ms per pass against 10.66 ms for one plain block - the fifteen launches' ramps and tails
+    // cost more than the placement gains: an experiment knob, CBA_EVAL_SEGMENTS=1 in an EXPERIMENTS build)
+    static const bool segmented = [] { const char* v = cba_exp_env("CBA_EVAL_SEGMENTS"); return v && atoi(v) != 0; }();
+    if (e.eval_blocked && segmented && jn * sizeof(double) > (size_t(4) << 30)) {  // segments of whole tiles, each <= 4 GiB and contiguous
+        const int64_t per = static_cast<int64_t>((size_t(4) << 30) / (tw * sizeof(double))) / 64 * 64;
+        const size_t nseg = static_cast<size_t>((e.n_tilesA + per - 1) / per);
+        if (e.seg_tiles != per || e.Jseg.size() != nseg) {
+            e.J.release();
+            e.Jseg.clear();
+            e.Jseg.resize(nseg);
+            for (size_t k = 0; k < nseg; ++k) {
+                const int64_t nt = std::min<int64_t>(per, e.n_tilesA - static_cast<int64_t>(k) * per);
+                alloc_output(e.Jseg[k], static_cast<size_t>(nt) * tw);
+            }
+            e.seg_tiles = per;
+        }
+        return;
+    }
+    if (!e.Jseg.empty()) { e.Jseg.clear(); e.seg_tiles = 0; }
     if (e.J.n < jn) alloc_output(e.J, jn);
 }
 
@@ -599,7 +619,7 @@ static void fetch_blocked_range(Engine& e, int b0, int b1, double* r, double* J)
     for (int b = b0; b < b1; ++b) {
         const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
         for (int64_t s0 = 0; s0 < n; s0 += TILE_A, ++w) {
-            CBA_HIP(hipMemcpyAsync(buf.data(), e.J.p + w * tw, sizeof(double) * tw, hipMemcpyDeviceToHost, e.stream));
+            CBA_HIP(hipMemcpyAsync(buf.data(), e.eval_tile_ptr(w, tw), sizeof(double) * tw, hipMemcpyDeviceToHost, e.stream));
             CBA_HIP(hipStreamSynchronize(e.stream));
             const int64_t cnt = std::min<int64_t>(TILE_A, n - s0);
             for (int64_t j = 0; j < cnt; ++j) {
@@ -620,7 +640,7 @@ cba_status cba_reproj_eval_fetch_blocks(cba_reproj* h, int32_t b0, int32_t b1, d
         Engine& e = *as_engine(h);
         CBA_HIP(hipSetDevice(e.device));
         if (e.scalar) throw std::runtime_error("fp32 arithmetic selected: use cba_reproj_eval_fetch_f32");
-        if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
+        if ((e.J.n == 0 && e.Jseg.empty()) || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
         if (b0 < 0 || b1 < b0 || b1 > e.n_blocks) throw std::invalid_argument("block range outside the problem");
         if (!e.eval_blocked_last) throw std::runtime_error("block-range fetch needs the tile-blocked output layout (the default)");
         fetch_blocked_range(e, b0, b1, r, J);
@@ -632,7 +652,7 @@ cba_status cba_reproj_eval_fetch(cba_reproj* h, double* r, double* J) {
         Engine& e = *as_engine(h);
         CBA_HIP(hipSetDevice(e.device));
         if (e.scalar) throw std::runtime_error("fp32 arithmetic selected: use cba_reproj_eval_fetch_f32");
-        if (e.J.n == 0 || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
+        if ((e.J.n == 0 && e.Jseg.empty()) || !e.eval_done) throw std::runtime_error("cba_reproj_eval has not been called");
         const int P = e.PL;
         if (e.eval_blocked_last) {
             fetch_blocked_range(e, 0, e.n_blocks, r, J);

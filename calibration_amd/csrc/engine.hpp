@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <deque>
 #include <cstdlib>
 #include <exception>
 #include <stdexcept>
@@ -195,6 +196,15 @@ struct Engine {
 
     // ---- device ------------------------------------------------------------------------------
     DevBuf<double> X, Y, u, v, r, J;
+    // A tile-blocked Mode A output above 4 GiB is held as SEGMENTS of whole tiles, each a physically contiguous block of at most
+    // 4 GiB (capi.cpp alloc_output: such blocks stream at the rate the memory system was laid out for and cost a millisecond to
+    // obtain; one contiguous block of 59 GB costs 1.7 s, a plain one runs 5-8 % slower).  k_eval is launched once per segment with
+    // the segment's tile range and base address: the kernel is unchanged.  Empty when the output is one block (J).
+    std::deque<DevBuf<double>> Jseg;
+    int64_t seg_tiles = 0;  // tiles per segment (the last one may hold fewer)
+    double* eval_tile_ptr(int64_t w, int64_t tile_doubles) {  // device address of tile w's output
+        return Jseg.empty() ? J.p + w * tile_doubles : Jseg[static_cast<size_t>(w / seg_tiles)].p + (w % seg_tiles) * tile_doubles;
+    }
     // fp32 study (BASELINE config 5): rounded copies of the observations / constant tables, fp32 Mode A output
     int scalar = 0;  // 0 = fp64 per-observation arithmetic, 1 = fp32 (accumulators stay fp64)
     DevBuf<float> Xf, Yf, uf, vf, Jf, bcf, sdf, intrf;

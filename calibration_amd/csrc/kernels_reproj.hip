@@ -440,21 +440,31 @@ static const double* intr_of(Engine& e) { return e.intr[e.active].p; }
 
 template <int C, int M, bool NT, int ROWS>
 static void launch_eval_v(Engine& e) {
-    const unsigned g = blocks_for(e.n_tilesA, 4 * ROWS);
-#define CBA_EVAL_ARGS dim3(g), dim3(256), 0, e.stream, e.tilesA.p, e.n_tilesA, e.bc.p, intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, \
-                      e.Y.p, e.u.p, e.v.p, e.r.p, e.J.p, e.ld
+    // one launch per output segment (engine.hpp Jseg: a blocked output above 4 GiB is a few contiguous blocks of whole tiles): the
+    // kernel indexes its output by the tile number relative to the tile table it is given
+    const int64_t tw = static_cast<int64_t>(2 + 2 * e.PL) * TILE_A;
+    const size_t nseg = e.Jseg.empty() ? 1 : e.Jseg.size();
+    for (size_t k = 0; k < nseg; ++k) {
+        const int64_t t0 = e.Jseg.empty() ? 0 : static_cast<int64_t>(k) * e.seg_tiles;
+        const int64_t nt = e.Jseg.empty() ? e.n_tilesA : std::min<int64_t>(e.seg_tiles, e.n_tilesA - t0);
+        double* Jk = e.Jseg.empty() ? e.J.p : e.Jseg[k].p;
+        (void)tw;
+        const unsigned g = blocks_for(nt, 4 * ROWS);
+#define CBA_EVAL_ARGS dim3(g), dim3(256), 0, e.stream, e.tilesA.p + t0, nt, e.bc.p, intr_of(e), e.sd.p, e.d_blk_cam.p, e.X.p, \
+                      e.Y.p, e.u.p, e.v.p, e.r.p, Jk, e.ld
 #ifdef CBA_EXPERIMENTS  // timing-only ablations of k_eval (outputs are wrong): experiment builds only
-    if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 1)
-        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), CBA_EVAL_ARGS);
-    else if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 2)
-        hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), CBA_EVAL_ARGS);
-    else
+        if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 1)
+            hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 1>), CBA_EVAL_ARGS);
+        else if (ROWS == 1 && NT && e.eval_blocked && e.eval_ablate == 2)
+            hipLaunchKernelGGL((k_eval<C, M, NT, 1, true, 2>), CBA_EVAL_ARGS);
+        else
 #endif
-    if (e.eval_blocked)
-        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), CBA_EVAL_ARGS);
-    else
-        hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), CBA_EVAL_ARGS);
+        if (e.eval_blocked)
+            hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, true>), CBA_EVAL_ARGS);
+        else
+            hipLaunchKernelGGL((k_eval<C, M, NT, ROWS, false>), CBA_EVAL_ARGS);
 #undef CBA_EVAL_ARGS
+    }
 }
 
 template <int C, int M>
