@@ -217,6 +217,9 @@ PROTOTYPES = {
     "cba_estimate_and_optimize_handeye_sharded": (
         C.c_int32, [C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, C.POINTER(CbaOptions), C.POINTER(CbaSummary),
                     c_double_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "cba_estimate_and_optimize_handeye_rccl": (
+        C.c_int32, [C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, C.POINTER(CbaOptions), C.POINTER(CbaSummary),
+                    c_double_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32]),
     "cba_optimize_handeye": (
         C.c_int32,
         [C.c_int32, c_double_p, c_double_p, c_double_p, C.POINTER(CbaOptions), C.POINTER(CbaSummary), c_double_p],

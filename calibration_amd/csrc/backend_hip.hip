@@ -1352,6 +1352,21 @@ void rccl_unique_id(uint8_t* id) {
     std::memcpy(id, &u, sizeof(u));
 }
 
+void* rccl_comm_create(const uint8_t* id, int n_ranks, int rank) {
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm;
+    const ncclResult_t r = ncclCommInitRank(&comm, n_ranks, u, rank);
+    if (r != ncclSuccess) throw HipError(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return comm;
+}
+void rccl_comm_destroy(void* comm, bool abort) {
+    if (!comm) return;
+    if (abort) (void)ncclCommAbort(reinterpret_cast<ncclComm_t>(comm));
+    else (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm));
+}
+
 void rccl_init(Engine& e, const uint8_t* id, int n_ranks, int rank) {
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
     rccl_destroy(e);

@@ -938,6 +938,28 @@ cba_status cba_estimate_and_optimize_handeye_sharded(int32_t n_poses, const doub
     });
 }
 
+cba_status cba_estimate_and_optimize_handeye_rccl(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                                  double min_angle_deg, int32_t estimate, double* g_T_c, const cba_options* opts,
+                                                  cba_summary* summary, double* cov, const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES],
+                                                  int32_t n_ranks, int32_t rank, int32_t device) {
+    return guarded([&] {
+        if (!opts || !summary || !g_T_c || !id) throw std::invalid_argument("null argument");
+        const int ndev = device_count();
+        if (ndev <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+        if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+        CBA_HIP(hipSetDevice(device));
+        void* comm = rccl_comm_create(id, n_ranks, rank);
+        try {
+            if (estimate) handeye_dlt(n_poses, base_T_gripper, cam_T_target, min_angle_deg, g_T_c, device, nullptr, nullptr, n_ranks, rank, comm);
+            handeye_solve(n_poses, base_T_gripper, cam_T_target, g_T_c, opts, summary, cov, device, nullptr, nullptr, n_ranks, rank, comm);
+        } catch (...) {
+            rccl_comm_destroy(comm, true);  // this rank leaves: its peers' collectives must fail, not hang
+            throw;
+        }
+        rccl_comm_destroy(comm, false);
+    });
+}
+
 cba_status cba_optimize_planar_pose_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
                                           const double* u, const double* v, const double* kmtx5, int32_t num_radial,
                                           double* pose7, const cba_options* opts, cba_summary* summaries, double* distortion,

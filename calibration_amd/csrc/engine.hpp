@@ -298,9 +298,13 @@ void dlt_homography_batch(int n_views, const int64_t* view_offset, const double*
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                        const double* kmtx5, double* pose7, int device);
 // fn / user / n_ranks / rank: multi-GPU form — this rank's share of the pairs, sums all-reduced through the host callback
+// (rccl_comm: an ncclComm_t over the ranks' devices - the sums are all-reduced on the device instead of through fn)
 void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device,
-                 cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0);
+                 cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0, void* rccl_comm = nullptr);
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
-                   double* cov, int device, cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0);
+                   double* cov, int device, cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1, int rank = 0,
+                   void* rccl_comm = nullptr);
+void* rccl_comm_create(const uint8_t* id, int n_ranks, int rank);  // backend_hip.hip: ncclCommInitRank on the current device
+void rccl_comm_destroy(void* comm, bool abort);
 
 }  // namespace cba

@@ -6,6 +6,8 @@
 // pair filter, evaluates residual + analytic tangent Jacobian, applies the per-pair Huber weight and
 // accumulates [H | g | cost | count] — wave-shuffle + LDS reduction per workgroup, then a fixed-order
 // two-level sum over workgroups (no atomics; bitwise reproducible).  Compute-bound: ~1.2 kFLOP per pair.
+#include <rccl/rccl.h>
+
 #include "engine.hpp"
 #include "handeye_core.hpp"
 #include "seed_math.hpp"
@@ -83,11 +85,12 @@ struct HipAxxb final : AxxbEval {
     int i_first = 0;              // first poses [i_first, i_first + grid.y) are this rank's (axxb_rank_range)
     cba_allreduce_fn reduce = nullptr;  // in-place sum of the 29 accumulated values over ranks (host callback)
     void* reduce_user = nullptr;
+    void* rccl = nullptr;               // ... or an RCCL communicator: ncclAllReduce of the device-resident sums on this stream
     HipAxxb(int n_poses, const double* bTg, const double* cTt, cba_allreduce_fn fn = nullptr, void* user = nullptr, int n_ranks = 1,
-            int rank = 0)
-        : n(n_poses), reduce(n_ranks > 1 ? fn : nullptr), reduce_user(user) {
+            int rank = 0, void* rccl_comm = nullptr)
+        : n(n_poses), reduce(n_ranks > 1 ? fn : nullptr), reduce_user(user), rccl(rccl_comm) {
         if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
-        if (n_ranks > 1 && !fn) throw std::invalid_argument("multi-rank AX = XB needs an all-reduce callback");
+        if (n_ranks > 1 && !fn && !rccl_comm) throw std::invalid_argument("multi-rank AX = XB needs an all-reduce callback or an RCCL communicator");
         int i_last = std::max(1, n - 1);
         if (n_ranks > 1) axxb_rank_range(n, n_ranks, rank, &i_first, &i_last);
         std::vector<double> h(static_cast<size_t>(n) * 24);
@@ -117,12 +120,20 @@ struct HipAxxb final : AxxbEval {
             hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(static_cast<unsigned>(n_chunks)), dim3(256), 0, stream, n_rows, int64_t{64}, partial.p, partial2.p);
             hipLaunchKernelGGL(k_axxb_chunk_sum, dim3(1), dim3(256), 0, stream, n_chunks, n_chunks, partial2.p, out.p);
             CBA_HIP(hipGetLastError());
+        } else if (rccl) {
+            CBA_HIP(hipMemsetAsync(out.p, 0, AXXB_NACC * sizeof(double), stream));  // this rank has no pairs: it contributes zeros
+        }
+        if (rccl) {  // the sum over ranks on the device, in place, on this stream: no host staging before the one copy back
+            const ncclResult_t r = ncclAllReduce(out.p, out.p, AXXB_NACC, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(rccl), stream);
+            if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        }
+        if (grid.y > 0 || rccl) {
             out.download(acc, AXXB_NACC, stream);
             CBA_HIP(hipStreamSynchronize(stream));
         } else {
             for (int e = 0; e < AXXB_NACC; ++e) acc[e] = 0.0;
         }
-        if (reduce && reduce(acc, AXXB_NACC, reduce_user) != 0) throw std::runtime_error("allreduce callback failed");
+        if (reduce && !rccl && reduce(acc, AXXB_NACC, reduce_user) != 0) throw std::runtime_error("allreduce callback failed");
     }
     ~HipAxxb() override { (void)hipStreamSynchronize(stream); }
     void eval(const double* pose7, double huber_delta, double* acc) override {
@@ -139,11 +150,11 @@ struct HipAxxb final : AxxbEval {
 // estimate_handeye_dlt (handeyedlt.cpp:126-137): two passes over all pose pairs on the device (rotation sums, then
 // translation sums at the estimated R_X), two 3x3 ridge solves on the host.  pose7 out.
 void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_angle_deg, double* pose7, int device, cba_allreduce_fn fn,
-                 void* user, int n_ranks, int rank) {
+                 void* user, int n_ranks, int rank, void* rccl_comm) {
     if (n_poses < 2 || !bTg || !cTt)  // handeyedlt.cpp:56-58
         throw std::runtime_error("Inconsistent hand-eye input sizes");
     CBA_HIP(hipSetDevice(device));
-    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank);
+    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank, rccl_comm);
     const double min_angle = min_angle_deg * 3.14159265358979323846 / 180.0;
     auto pass = [&](int mode, const double* RX, double* acc) {
         double hx[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
@@ -165,11 +176,11 @@ void handeye_dlt(int n_poses, const double* bTg, const double* cTt, double min_a
 }
 
 void handeye_solve(int n_poses, const double* bTg, const double* cTt, double* pose7, const cba_options* o, cba_summary* s,
-                   double* cov, int device, cba_allreduce_fn fn, void* user, int n_ranks, int rank) {
+                   double* cov, int device, cba_allreduce_fn fn, void* user, int n_ranks, int rank, void* rccl_comm) {
     if (n_poses < 2 || !bTg || !cTt)  // handeyedlt.cpp:56-58
         throw std::runtime_error("Inconsistent hand-eye input sizes");
     CBA_HIP(hipSetDevice(device));
-    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank);
+    HipAxxb ev(n_poses, bTg, cTt, fn, user, n_ranks, rank, rccl_comm);
     handeye_lm(ev, pose7, *o, s, (cov && o->compute_covariance) ? cov : nullptr);
 }
 

@@ -564,6 +564,28 @@ def optimize_handeye_sharded(base_se3_gripper, camera_se3_target, allreduce, n_r
     return HandeyeResult(result_core(s, cov if options.compute_covariance else None), pose_to_matrix(x))
 
 
+def optimize_handeye_rccl(base_se3_gripper, camera_se3_target, rccl_id: bytes, n_ranks: int, rank: int, init_gripper_se3_ref=None,
+                          min_angle_deg: float = 1.0, options: Optional[OptimOptions] = None, device: int = 0) -> HandeyeResult:
+    """The sharded AX = XB solve with RCCL over xGMI as the transport (cba_estimate_and_optimize_handeye_rccl): ``rccl_id`` is the
+    128-byte id of rccl_unique_id(), created by one rank and distributed by the caller; every rank calls this (a collective)."""
+    options = options or OptimOptions()
+    lib = capi.load_library()
+    n = len(base_se3_gripper)
+    if len(camera_se3_target) != n:
+        raise capi.CbaError(capi.CBA_ERR_RUNTIME, "Inconsistent hand-eye input sizes")
+    bg = np.stack([pose_from_matrix(m) for m in base_se3_gripper]) if n else np.zeros((0, 7))
+    ct = np.stack([pose_from_matrix(m) for m in camera_se3_target]) if n else np.zeros((0, 7))
+    x = np.zeros(7) if init_gripper_se3_ref is None else pose_from_matrix(init_gripper_se3_ref)
+    copts = to_cba_options(options)
+    s = CbaSummary()
+    cov = np.zeros((7, 7))
+    idbuf = (C.c_uint8 * capi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(rccl_id))
+    capi.check(lib, lib.cba_estimate_and_optimize_handeye_rccl(
+        n, dptr(bg), dptr(ct), float(min_angle_deg), 1 if init_gripper_se3_ref is None else 0, dptr(x), C.byref(copts), C.byref(s),
+        dptr(cov) if options.compute_covariance else dptr(None), idbuf, int(n_ranks), int(rank), int(device)))
+    return HandeyeResult(result_core(s, cov if options.compute_covariance else None), pose_to_matrix(x))
+
+
 def estimate_handeye_dlt(base_se3_gripper, camera_se3_target, min_angle_deg: float = 1.0) -> np.ndarray:
     """estimate_handeye_dlt (linear/handeye.h, handeyedlt.cpp:126-137): all-pairs Tsai-Lenz seed, pairs enumerated on the GPU."""
     lib = capi.load_library()

@@ -316,6 +316,17 @@ cba_status cba_estimate_and_optimize_handeye_sharded(int32_t n_poses, const doub
                                                      const cba_options* opts, cba_summary* summary, double* cov,
                                                      cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank, int32_t device);
 
+/* ... and with RCCL over xGMI as the transport (BASELINE configs[3]: "8 MI355X"): `id` is the 128-byte unique id of
+ * cba_rccl_unique_id(), created by one rank and handed to all of them by the caller; every rank calls this entry point (it is a
+ * collective: the communicator is created inside, over the ranks' devices, and torn down at the end).  The 29 sums of every
+ * evaluation are reduced IN PLACE in device memory on the evaluation's stream (ncclAllReduce), then copied back once.  A rank
+ * that fails aborts the communicator so that its peers fail too instead of waiting. */
+cba_status cba_estimate_and_optimize_handeye_rccl(int32_t n_poses, const double* base_T_gripper, const double* cam_T_target,
+                                                  double min_angle_deg, int32_t estimate, double* g_T_c,
+                                                  const cba_options* opts, cba_summary* summary, double* cov,
+                                                  const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank,
+                                                  int32_t device);
+
 /* optimize_planar_pose (include/calib/estimation/optim/planarpose.h:24-26, src/estimation/optim/planarpose.cpp:84-127):
  * pose refinement of ONE planar view for fixed K = [fx, fy, cx, cy, skew] by variable projection over the
  * Brown-Conrady coefficients (num_radial radial + 2 tangential, PlanarPoseOptions::num_radial default 2).

@@ -391,6 +391,22 @@ def test_handeye_gpu_matches_oracle(gpu_lib, oracle, n_poses, noise):
     assert np.abs(ca - cb).max() <= 1e-6 * np.abs(ca).max()
 
 
+def test_handeye_rccl_transport_one_rank_equals_the_plain_entry_point(gpu_lib):
+    """cba_estimate_and_optimize_handeye_rccl (BASELINE configs[3] names 8 GPUs): the 29 sums of every evaluation go through
+    ncclAllReduce in device memory.  A one-GPU box can only run a communicator of one rank - the code path (communicator set-up,
+    in-place collective on the evaluation's stream, one copy back, tear-down) is the multi-rank one; the sharding arithmetic is
+    covered over gloo with 2 - 4 ranks (tests/test_multirank_gloo.py).  handeye.cpp:60-87."""
+    from calibration_amd.geometry import pose_from_matrix
+
+    bTg, cTt, _X_gt, _X0 = helpers.handeye_scene(40, seed=11, noise_rot_deg=0.05, noise_trans=0.0005)
+    ref = optim.estimate_and_optimize_handeye(bTg, cTt, 1.0, optim.OptimOptions(epsilon=1e-12))
+    res = optim.optimize_handeye_rccl(bTg, cTt, optim.rccl_unique_id(), 1, 0, init_gripper_se3_ref=None, min_angle_deg=1.0,
+                                      options=optim.OptimOptions(epsilon=1e-12), device=0)
+    assert res.core.success == ref.core.success and res.core.final_cost == ref.core.final_cost
+    assert np.array_equal(pose_from_matrix(res.g_se3_c), pose_from_matrix(ref.g_se3_c))
+    assert np.array_equal(res.core.covariance, ref.core.covariance)
+
+
 def test_handeye_degenerate_is_runtime_error_on_gpu(gpu_lib):
     with pytest.raises(capi.CbaError) as ei:
         optim.optimize_handeye([np.eye(4)] * 5, [np.eye(4)] * 5, np.eye(4))
