@@ -84,10 +84,9 @@ __global__ __launch_bounds__(256) void k_weights_cost(int n_blocks, int NACC, in
 }
 
 // partial[k][e] = sum over chunk k's blocks (in list order) of w_b * acc[b][e]
-__global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ cam_blk,
-                              const double* __restrict__ blk_w, const double* __restrict__ blk_acc,
-                              double* __restrict__ partial) {
-    const int k = blockIdx.x;
+__device__ __forceinline__ void cam_partial_body(int k, int NACC, const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ cam_blk,
+                                                 const double* __restrict__ blk_w, const double* __restrict__ blk_acc,
+                                                 double* __restrict__ partial) {
     const int64_t p0 = chunk_off[k], p1 = chunk_off[k + 1];
     for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
         double s = 0.0;
@@ -106,6 +105,11 @@ __global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, c
         }
         partial[static_cast<int64_t>(k) * NACC + e] = s;
     }
+}
+__global__ void k_cam_partial(int NACC, const int64_t* __restrict__ chunk_off, const int32_t* __restrict__ cam_blk,
+                              const double* __restrict__ blk_w, const double* __restrict__ blk_acc,
+                              double* __restrict__ partial) {
+    cam_partial_body(blockIdx.x, NACC, chunk_off, cam_blk, blk_w, blk_acc, partial);
 }
 
 // Column sums of a row-major partial table in a FIXED order, 8 row groups per column: thread (column c, group r)
@@ -129,13 +133,18 @@ __device__ __forceinline__ double grouped_column_sum(const double* __restrict__ 
 }
 
 // out[o][e] = sum_{t in [seg[o], seg[o+1])} rows[t][e]; grid (ceil(width / 32), n_out), 256 threads
-__global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_seg_sum(int n_out, int width, const int64_t* __restrict__ seg,
-                                                                  const double* __restrict__ rows, double* __restrict__ out) {
-    __shared__ double sh[RS_GROUPS][RS_COLS];
-    const int o = blockIdx.y;
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * RS_COLS + threadIdx.x % RS_COLS;
+__device__ __forceinline__ void seg_sum_body(double* lds, int bx, int o, int width, const int64_t* __restrict__ seg, const double* __restrict__ rows,
+                                             double* __restrict__ out) {
+    double (*sh)[RS_COLS] = reinterpret_cast<double (*)[RS_COLS]>(lds);
+    const int64_t e = static_cast<int64_t>(bx) * RS_COLS + threadIdx.x % RS_COLS;
     const double tot = grouped_column_sum(rows, seg[o], seg[o + 1], width, e, e < width, sh);
     if (threadIdx.x < RS_COLS && e < width) out[static_cast<int64_t>(o) * width + e] = tot;
+}
+__global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_seg_sum(int n_out, int width, const int64_t* __restrict__ seg,
+                                                                  const double* __restrict__ rows, double* __restrict__ out) {
+    __shared__ double lds[RS_GROUPS * RS_COLS];
+    (void)n_out;
+    seg_sum_body(lds, blockIdx.x, blockIdx.y, width, seg, rows, out);
 }
 
 // out[e] = sum_{t < n_rows} rows[t][e]; grid ceil(width / 32), 256 threads
@@ -149,10 +158,11 @@ __global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_row_sum(int64_t n_rows,
 
 // single workgroup: out[c] = sum_i in[i*w + c] (c < w <= 4); if aux: out[w] = max_i aux[i] and out[w + 1] = #{i : aux[i] < 0}
 // (k_schur_view marks a view whose damped H_pp is not positive definite with -1).  `out` may be page-locked host memory.
-__global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
-                                                    double* __restrict__ out, const double* __restrict__ gate = nullptr) {
-    __shared__ double sh[6][256];
-    if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
+constexpr int COL_REDUCE_LDS = 6 * 256;  // doubles of LDS scratch (the fused stages hand every body a piece of ONE buffer: the
+                                         // compiler does not overlay the static LDS of branches that exclude each other)
+__device__ __forceinline__ void col_reduce_body(double* lds, int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
+                                                double* __restrict__ out) {
+    double (*sh)[256] = reinterpret_cast<double (*)[256]>(lds);
     double acc[4] = {0, 0, 0, 0}, mx = 0.0, bad = 0.0;
     for (int i = static_cast<int>(threadIdx.x); i < n; i += 256) {
         for (int c = 0; c < w; ++c) acc[c] += in[static_cast<int64_t>(i) * w + c];
@@ -174,6 +184,12 @@ __global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* 
         for (int c = 0; c < w; ++c) out[c] = sh[c][0];
         if (aux) { out[w] = sh[4][0]; out[w + 1] = sh[5][0]; }
     }
+}
+__global__ __launch_bounds__(256) void k_col_reduce(int n, int w, const double* __restrict__ in, const double* __restrict__ aux,
+                                                    double* __restrict__ out, const double* __restrict__ gate = nullptr) {
+    __shared__ double lds[COL_REDUCE_LDS];
+    if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
+    col_reduce_body(lds, n, w, in, aux, out);
 }
 
 __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
@@ -199,14 +215,14 @@ __global__ void k_schur_view(SchurDims d, int n_views, const int64_t* __restrict
 // few views there are (8-camera rig: 8 blocks x 16 shared columns of forward substitutions per view, 107 us for 500 views and 84 us
 // for 4000): here every lane runs the short factor part redundantly and the lanes split the (block, column) pairs of Z.  Same
 // operations per value as the serial body: bit-identical results.
-__global__ __launch_bounds__(256) void k_schur_view_wave(SchurDims d, int n_views, const int64_t* __restrict__ link_off,
-                                                         const int32_t* __restrict__ link_blk, const double* __restrict__ blk_acc,
-                                                         const double* __restrict__ blk_w, const int32_t* __restrict__ fixed,
-                                                         const double* __restrict__ lmp, int constrained, const double* __restrict__ view,
-                                                         double* __restrict__ scale2, double* __restrict__ L, double* __restrict__ y,
-                                                         double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
-                                                         double* __restrict__ gmax) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void schur_view_wave_body(int bx, const SchurDims& d, int n_views, const int64_t* __restrict__ link_off,
+                                                     const int32_t* __restrict__ link_blk, const double* __restrict__ blk_acc,
+                                                     const double* __restrict__ blk_w, const int32_t* __restrict__ fixed,
+                                                     const double* __restrict__ lmp, int constrained, const double* __restrict__ view,
+                                                     double* __restrict__ scale2, double* __restrict__ L, double* __restrict__ y,
+                                                     double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
+                                                     double* __restrict__ gmax) {
+    const int v = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= n_views) return;
     const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
     const int32_t* blks = link_blk + link_off[v];
@@ -239,6 +255,15 @@ __global__ __launch_bounds__(256) void k_schur_view_wave(SchurDims d, int n_view
         const int b = blks[k];
         schur_view_zcol(d, F, rd, blk_w[b], blk_acc + static_cast<int64_t>(b) * d.NACC, c, blk_Z + static_cast<int64_t>(b) * 6 * d.PSH);
     }
+}
+__global__ __launch_bounds__(256) void k_schur_view_wave(SchurDims d, int n_views, const int64_t* __restrict__ link_off,
+                                                         const int32_t* __restrict__ link_blk, const double* __restrict__ blk_acc,
+                                                         const double* __restrict__ blk_w, const int32_t* __restrict__ fixed,
+                                                         const double* __restrict__ lmp, int constrained, const double* __restrict__ view,
+                                                         double* __restrict__ scale2, double* __restrict__ L, double* __restrict__ y,
+                                                         double* __restrict__ D, double* __restrict__ gp, double* __restrict__ blk_Z,
+                                                         double* __restrict__ gmax) {
+    schur_view_wave_body(blockIdx.x, d, n_views, link_off, link_blk, blk_acc, blk_w, fixed, lmp, constrained, view, scale2, L, y, D, gp, blk_Z, gmax);
 }
 
 // ... and the back-substitution: the lanes split a = Z d_c over the (block, column) pairs (fixed assignment, fixed-order DPP
@@ -318,17 +343,16 @@ __device__ __forceinline__ void schur_gvec_chunk(const double (*Zs)[64], const d
 
 // grid (view chunks, upper tile pairs); 256 threads = 16x16, each a 4x4 micro-tile of a 64x64 tile.
 // partial[chunk] = [pair][64*64] then g_schur[nsh]  (row stride n_pairs * 4096 + nsh)
-__global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, int nsh, int n_tiles,
-                                                    const int32_t* __restrict__ view_cam_blk,
-                                                    const double* __restrict__ blk_Z, const double* __restrict__ y,
-                                                    double* __restrict__ partial) {
+constexpr int SYRK_LDS = 2 * 6 * VCHUNK * 64 + 6 * VCHUNK + VCHUNK * SYRK_MAX_CAMS / 2;  // doubles: Zi | Zj | y | block table (ints)
+__device__ __forceinline__ void schur_syrk_body(double* lds, int bx, int by, int gy, const SchurDims& d, int n_views, int nsh, int n_tiles,
+        const int32_t* __restrict__ view_cam_blk, const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
     // the chunk's 6 * VCHUNK rows of Z are staged in one go (one barrier per workgroup, not two per view: the staging of a
     // 10-wide shared block is all latency); the products are added in the same (view, k) order as before
-    __shared__ double Zi[6 * VCHUNK][64], Zj[6 * VCHUNK][64];
-    __shared__ double ysh[6 * VCHUNK];
-    __shared__ int bsh[VCHUNK * SYRK_MAX_CAMS];
+    double (*Zi)[64] = reinterpret_cast<double (*)[64]>(lds), (*Zj)[64] = Zi + 6 * VCHUNK;
+    double* ysh = lds + 2 * 6 * VCHUNK * 64;
+    int* bsh = reinterpret_cast<int*>(ysh + 6 * VCHUNK);
     // decode the upper-triangular tile pair
-    int pair = blockIdx.y, ti = 0;
+    int pair = by, ti = 0;
     while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
     const int tj = ti + pair;
     const int i0 = ti * 64, j0 = tj * 64;
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    const int v0 = blockIdx.x * VCHUNK;
+    const int v0 = bx * VCHUNK;
     const int nrow = 6 * (min(n_views, v0 + VCHUNK) - v0);
     stage_block_table(d, n_views, v0, view_cam_blk, bsh);
     __syncthreads();
@@ -356,13 +380,18 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
     }
-    double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
-    double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
+    double* row = partial + static_cast<int64_t>(bx) * (static_cast<int64_t>(gy) * 4096 + nsh);
+    double* out = row + static_cast<int64_t>(by) * 4096;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
-    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gridDim.y) * 4096);
+    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gy) * 4096);
+}
+__global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, int nsh, int n_tiles, const int32_t* __restrict__ view_cam_blk,
+        const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
+    __shared__ double lds[SYRK_LDS];
+    schur_syrk_body(lds, blockIdx.x, blockIdx.y, gridDim.y, d, n_views, nsh, n_tiles, view_cam_blk, blk_Z, y, partial);
 }
 
 // The same contraction on the matrix cores, used when the shared block is a real contraction (nsh >= 64: the 8-camera rig of
@@ -374,18 +403,16 @@ __global__ __launch_bounds__(256) void k_schur_syrk(SchurDims d, int n_views, in
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int SYRK_ROWS = 6 * VCHUNK;  // 48, a multiple of 4
 
-__global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_views, int nsh, int n_tiles,
-                                                         const int32_t* __restrict__ view_cam_blk,
-                                                         const double* __restrict__ blk_Z, const double* __restrict__ y,
-                                                         double* __restrict__ partial) {
-    __shared__ double Zi[SYRK_ROWS][64], Zj[SYRK_ROWS][64];
-    __shared__ double ysh[SYRK_ROWS];
-    __shared__ int bsh[VCHUNK * SYRK_MAX_CAMS];
-    int pair = blockIdx.y, ti = 0;
+__device__ __forceinline__ void schur_syrk_mfma_body(double* lds, int bx, int by, int gy, const SchurDims& d, int n_views, int nsh, int n_tiles,
+        const int32_t* __restrict__ view_cam_blk, const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
+    double (*Zi)[64] = reinterpret_cast<double (*)[64]>(lds), (*Zj)[64] = Zi + SYRK_ROWS;
+    double* ysh = lds + 2 * SYRK_ROWS * 64;
+    int* bsh = reinterpret_cast<int*>(ysh + SYRK_ROWS);
+    int pair = by, ti = 0;
     while (pair >= n_tiles - ti) { pair -= n_tiles - ti; ++ti; }
     const int tj = ti + pair;
     const int i0 = ti * 64, j0 = tj * 64;
-    const int v0 = blockIdx.x * VCHUNK;
+    const int v0 = bx * VCHUNK;
     stage_block_table(d, n_views, v0, view_cam_blk, bsh);
     __syncthreads();
     stage_Z(d, bsh, n_views, v0, view_cam_blk, blk_Z, i0, nsh, Zi);
@@ -406,13 +433,18 @@ __global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_view
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zc[r][c * 16 + li], acc[c], 0, 0, 0);
     }
-    double* row = partial + static_cast<int64_t>(blockIdx.x) * (static_cast<int64_t>(gridDim.y) * 4096 + nsh);
-    double* out = row + static_cast<int64_t>(blockIdx.y) * 4096;
+    double* row = partial + static_cast<int64_t>(bx) * (static_cast<int64_t>(gy) * 4096 + nsh);
+    double* out = row + static_cast<int64_t>(by) * 4096;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) out[(wave * 16 + lk + 4 * reg) * 64 + c * 16 + li] = acc[c][reg];
-    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gridDim.y) * 4096);
+    if (ti == tj) schur_gvec_chunk(Zi, ysh, nrow, i0, nsh, row + static_cast<int64_t>(gy) * 4096);
+}
+__global__ __launch_bounds__(256) void k_schur_syrk_mfma(SchurDims d, int n_views, int nsh, int n_tiles, const int32_t* __restrict__ view_cam_blk,
+        const double* __restrict__ blk_Z, const double* __restrict__ y, double* __restrict__ partial) {
+    __shared__ double lds[SYRK_LDS];
+    schur_syrk_mfma_body(lds, blockIdx.x, blockIdx.y, gridDim.y, d, n_views, nsh, n_tiles, view_cam_blk, blk_Z, y, partial);
 }
 
 __global__ void k_backsub(SchurDims d, int n_views, const int64_t* __restrict__ link_off, const int32_t* __restrict__ link_blk,
@@ -479,6 +511,183 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a, const double* __restri
         pack[a.off_stats + 5] = a.has_stats == 2 ? stat[2] : 0.0;  // SLOPE
     }
     if (!a.has_blocks && tid < a.n_cam_doubles) pack[a.off_cam + tid] = 0.0;
+}
+
+// ---- the fused stages of one linear solve -----------------------------------------------------------------------------------------
+// Between Mode B and the packed exchange an LM step needs ten small dependent reductions (block weights and cost, per-camera sums,
+// per-view elimination, the Schur contraction and its sums, the pack).  As launches of their own each costs 4 - 6 us of dispatch
+// and drain whatever its work (87 us per step for the 8-camera rig, a sixth of a step when the problem is split over 8 GPUs).
+// Here the stages that do not depend on each other share ONE launch (ranges of blockIdx.x run different bodies), and every
+// reduction keeps its own fixed order: the results are bit-identical to the one-kernel-per-stage sequence, which the paths off
+// the LM loop (covariance, cost queries, the one-thread-per-view form) still use.
+//   k_step_head   back-substitution of the views + their blocks' constants at the trial poses      (was 3 launches)
+//   k_sys_stage2  per-camera chunk sums | per-view elimination | cost (or its partial sums)         (was 3)
+//   k_sys_stage3  camera segment sums | Schur contraction | gradient max | step statistics | cost   (was 4 - 5)
+//   k_sys_pack    sums over the view chunks straight into the packed exchange buffer                (was 2)
+struct SysArgs {
+    SchurDims d;
+    int n_views, n_blocks, nsh, n_tiles, n_pairs, n_vchunks, n_cams, NACC, constrained;
+    int n_cc, n_vb, n_costp;         // stage 2 ranges: camera chunks | view workgroups (4 views each) | cost workgroups (0, 1 or ceil(n_blocks / 2048))
+    int n_seg_x, n_seg, n_syrk;      // stage 3 ranges: segment sums (n_seg_x per camera) | (chunk, tile pair) | then 1 + has_vstats + (n_costp > 1)
+    int has_vstats;                  // the views' step statistics (k_step_head) are reduced in stage 3
+    double huber;
+    const int64_t *link_off, *cchunk_off, *cam_seg;
+    const int32_t *link_blk, *cam_blk, *view_fixed, *view_cam_blk;
+    const double *blk_acc, *blk_w, *blk_s, *lmp, *view;
+    double *view_scale2, *view_L, *view_y, *view_D, *view_gp, *blk_Z, *view_gmax, *cam_partial, *cam_out, *cost_part, *cost_out;
+    double *syrk_partial, *tiles_tail /* [gmax, #failed] */, *view_stats, *stat_out;
+};
+
+// {1/2 sum rho(s_b), sum s_b} over b = b0 + t, b0 + t + 256, ... < b1 (k_cost / k_cost_partial of kernels_reproj.hip: same strides, same tree)
+__device__ __forceinline__ void cost_range_body(double* lds, int b0, int b1, const double* __restrict__ blk_s, double huber_delta, double* __restrict__ out2) {
+    double (*sh)[256] = reinterpret_cast<double (*)[256]>(lds);
+    double c = 0.0, ss = 0.0;
+    for (int b = b0 + static_cast<int>(threadIdx.x); b < b1; b += 256) {
+        double rho, w;
+        huber(blk_s[b], huber_delta, &rho, &w);
+        c += 0.5 * rho;
+        ss += blk_s[b];
+    }
+    sh[0][threadIdx.x] = c;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = sh[0][0]; out2[1] = sh[1][0]; }
+}
+
+__global__ __launch_bounds__(256) void k_sys_stage2(SysArgs a) {
+    __shared__ double lds[2 * 256];
+    int bx = blockIdx.x;
+    if (bx < a.n_cc) {
+        cam_partial_body(bx, a.NACC, a.cchunk_off, a.cam_blk, a.blk_w, a.blk_acc, a.cam_partial);
+        return;
+    }
+    bx -= a.n_cc;
+    if (bx < a.n_vb) {
+        schur_view_wave_body(bx, a.d, a.n_views, a.link_off, a.link_blk, a.blk_acc, a.blk_w, a.view_fixed, a.lmp, a.constrained, a.view,
+                             a.view_scale2, a.view_L, a.view_y, a.view_D, a.view_gp, a.blk_Z, a.view_gmax);
+        return;
+    }
+    bx -= a.n_vb;
+    if (a.n_costp == 1) cost_range_body(lds, 0, a.n_blocks, a.blk_s, a.huber, a.cost_out);
+    else cost_range_body(lds, bx * 2048, min(bx * 2048 + 2048, a.n_blocks), a.blk_s, a.huber, a.cost_part + 2 * bx);
+}
+
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_sys_stage3(SysArgs a) {
+    __shared__ double lds[SYRK_LDS];
+    static_assert(SYRK_LDS >= COL_REDUCE_LDS && SYRK_LDS >= RS_GROUPS * RS_COLS, "one LDS buffer for every body");
+    int bx = blockIdx.x;
+    if (bx < a.n_seg) {
+        seg_sum_body(lds, bx % a.n_seg_x, bx / a.n_seg_x, a.NACC, a.cam_seg, a.cam_partial, a.cam_out);
+        return;
+    }
+    bx -= a.n_seg;
+    if (bx < a.n_syrk) {
+        const int chunk = bx % a.n_vchunks, pair = bx / a.n_vchunks;
+        if (MFMA) schur_syrk_mfma_body(lds, chunk, pair, a.n_pairs, a.d, a.n_views, a.nsh, a.n_tiles, a.view_cam_blk, a.blk_Z, a.view_y, a.syrk_partial);
+        else schur_syrk_body(lds, chunk, pair, a.n_pairs, a.d, a.n_views, a.nsh, a.n_tiles, a.view_cam_blk, a.blk_Z, a.view_y, a.syrk_partial);
+        return;
+    }
+    bx -= a.n_syrk;
+    if (bx == 0) { col_reduce_body(lds, a.n_views, 0, a.view_gmax, a.view_gmax, a.tiles_tail); return; }
+    if (bx == 1 && a.has_vstats) { col_reduce_body(lds, a.n_views, 4, a.view_stats, nullptr, a.stat_out); return; }
+    if (threadIdx.x == 0) {  // k_cost_final: the partial pairs in order
+        double c = 0.0, ss = 0.0;
+        for (int k = 0; k < a.n_costp; ++k) { c += a.cost_part[2 * k]; ss += a.cost_part[2 * k + 1]; }
+        a.cost_out[0] = c;
+        a.cost_out[1] = ss;
+    }
+}
+
+// k_row_sum and k_pack in one: workgroup x sums 32 columns of the chunk table [n_vchunks][pairs * 4096 + nsh] (8 row groups, fixed
+// order) and writes each straight to its place in the pack (S as its packed upper triangle, g_schur); workgroup 0 adds the scalars
+__global__ __launch_bounds__(RS_COLS * RS_GROUPS) void k_sys_pack(PackArgs a, int64_t n_rows, const double* __restrict__ rows,
+                                                                   const double* __restrict__ tail /*[gmax, #failed]*/,
+                                                                   const double* __restrict__ stat, double* __restrict__ pack) {
+    __shared__ double sh[RS_GROUPS][RS_COLS];
+    const int64_t sw = static_cast<int64_t>(a.n_tiles) * (a.n_tiles + 1) / 2 * 4096, width = sw + a.n;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * RS_COLS + threadIdx.x % RS_COLS;
+    const double tot = grouped_column_sum(rows, 0, n_rows, width, e, e < width, sh);
+    if (threadIdx.x < RS_COLS && e < width) {
+        if (e < sw) {
+            int pair = static_cast<int>(e >> 12), ti = 0;
+            while (pair >= a.n_tiles - ti) { pair -= a.n_tiles - ti; ++ti; }
+            const int i = ti * 64 + static_cast<int>((e >> 6) & 63), j = (ti + pair) * 64 + static_cast<int>(e & 63);
+            if (i <= j && j < a.n) pack[a.off_S + ctl_sidx(a.n, i, j)] = tot;
+        } else {
+            pack[a.off_g + (e - sw)] = tot;
+        }
+    }
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid < a.n_ranks) pack[a.off_gmax + tid] = tid == a.rank ? tail[0] : 0.0;
+    if (tid == 0) {
+        pack[a.off_nfail] = tail[1];
+        pack[a.off_cost] = a.has_cost ? stat[4] : 0.0;
+        pack[a.off_stats + 0] = a.has_stats == 1 ? stat[2] : 0.0;
+        pack[a.off_stats + 1] = a.has_stats == 1 ? stat[3] : 0.0;
+        pack[a.off_stats + 2] = a.has_stats ? stat[0] : 0.0;
+        pack[a.off_stats + 3] = a.has_stats ? stat[1] : 0.0;
+        pack[a.off_stats + 4] = (a.has_stats && a.has_cost) ? stat[4] : 0.0;
+        pack[a.off_stats + 5] = a.has_stats == 2 ? stat[2] : 0.0;
+    }
+    if (!a.has_blocks)
+        for (int64_t k = tid; k < a.n_cam_doubles; k += static_cast<int64_t>(gridDim.x) * blockDim.x) pack[a.off_cam + k] = 0.0;
+}
+
+// k_backsub_wave, then the constants of the view's residual blocks at its trial pose (k_block_consts' work: a block's constants
+// depend on its own view's pose and on the shared blocks the controller has left in copy 1) - the wavefront that has just formed
+// the pose hands it to its lanes through registers, lane k takes the view's k-th block.  INTRINSIC / EXTRINSIC chains (the
+// bundle chain has no private poses).
+template <int CHAIN>
+__global__ __launch_bounds__(256) void k_step_head(const double* __restrict__ gate, SchurDims d, int n_views, const int64_t* __restrict__ link_off,
+                                                   const int32_t* __restrict__ link_blk, const int32_t* __restrict__ blk_cam,
+                                                   const double* __restrict__ blk_Z, const double* __restrict__ delta_sh,
+                                                   const int32_t* __restrict__ fixed, const double* __restrict__ L, const double* __restrict__ y,
+                                                   const double* __restrict__ D, const double* __restrict__ gp, const double* __restrict__ x,
+                                                   double* __restrict__ delta_p, double* __restrict__ xt, double* __restrict__ stats,
+                                                   const double* __restrict__ cam_trial, double* __restrict__ bc) {
+    if (gate && *gate == 0.0) return;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n_views) return;
+    const int nb = static_cast<int>(link_off[v + 1] - link_off[v]);
+    const int32_t* blks = link_blk + link_off[v];
+    const bool fx = fixed[v] != 0;
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!fx) {
+        const int n_pairs = nb * d.PSH;
+        for (int p = lane; p < n_pairs; p += 64) {
+            const int k = p / d.PSH, c = p - k * d.PSH;
+            const int b = blks[k];
+            const double dc = delta_sh[blk_cam[b] * d.PC + c];
+            const double* Z = blk_Z + static_cast<int64_t>(b) * 6 * d.PSH + c;
+            for (int i = 0; i < 6; ++i) a[i] += Z[i * d.PSH] * dc;
+        }
+        for (int i = 0; i < 6; ++i) a[i] = wave_sum63(a[i]);  // total in lane 63
+    }
+    double pose[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane == 63) {
+        double o4[4], dp[6];
+        backsub_view_finish(fx, a, L + 36 * static_cast<int64_t>(v), y + 6 * static_cast<int64_t>(v), D + 6 * static_cast<int64_t>(v),
+                            gp + 6 * static_cast<int64_t>(v), x + 7 * static_cast<int64_t>(v), dp, pose, o4);
+        for (int k = 0; k < 6; ++k) delta_p[6 * static_cast<int64_t>(v) + k] = dp[k];
+        for (int k = 0; k < 7; ++k) xt[7 * static_cast<int64_t>(v) + k] = pose[k];
+        for (int k = 0; k < 4; ++k) stats[4 * static_cast<int64_t>(v) + k] = o4[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pose[k] = __shfl(pose[k], 63);
+    for (int k = lane; k < nb; k += 64) {
+        const int b = blks[k];
+        double out[BC_SIZE];
+        block_consts<CHAIN>(pose, CHAIN == CH_EXTRINSIC ? cam_trial + 7 * static_cast<int64_t>(blk_cam[b]) : nullptr, nullptr, out);
+        for (int i = 0; i < BC_SIZE; ++i) bc[static_cast<int64_t>(b) * BC_SIZE + i] = out[i];
+    }
 }
 
 // line search sample (line_search.hpp): trial poses at step size a along the last back-substituted step; stats [n_views][4] =
@@ -593,20 +802,31 @@ struct HipBackend final : Backend {
     }
     // which: parameter copy to linearise at; cam_out [n_cams][NACC] and cost_out {cost, sum s} may be device or page-locked host memory
     void enqueue_normal_eq(double huber, int which = 0, double* cam_out = nullptr, double* cost_out = nullptr) {
-        enqueue_normal_eq_head(which);
+        enqueue_normal_eq_head(which, huber);
         enqueue_normal_eq_tail(huber, cam_out, cost_out);
     }
-    void enqueue_normal_eq_head(int which) {  // block constants at copy `which`, Mode B: the per-block [H | g | s]
-        launch_block_consts(e, which);
-        launch_normal_eq(e);
+    // block constants at copy `which` (unless the caller has built them: k_step_head), Mode B: the per-block [H | g | s]; huber >= 0:
+    // the kernel that finishes a block's row also leaves its robust weight where it can (Engine::head_weights says whether it did)
+    void enqueue_normal_eq_head(int which, double huber = -1.0, bool consts_done = false) {
+        if (!consts_done) launch_block_consts(e, which);
+        e.head_huber = st.fuse_small ? huber : -1.0;
+        try {
+            launch_normal_eq(e);
+        } catch (...) {
+            e.head_huber = -1.0;
+            throw;
+        }
+        e.head_huber = -1.0;
     }
     void enqueue_normal_eq_tail(double huber, double* cam_out = nullptr, double* cost_out = nullptr) {  // weights, cost, per-camera sums
         const Structure& s = st.s;
         const size_t nca = static_cast<size_t>(s.n_cams) * s.NACC;
         if (!cam_out) cam_out = st.pin_ne.p;
         if (!cost_out) cost_out = st.pin_ne.p + nca;
-        const bool fused_cost = s.n_blocks <= 4096;
-        if (fused_cost)
+        const bool fused_cost = s.n_blocks <= 4096 && !e.head_weights;
+        if (e.head_weights)
+            ;  // the weights came with the block rows; the cost follows below
+        else if (fused_cost)
             hipLaunchKernelGGL(k_weights_cost, dim3(1), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL, e.blk_acc.p, huber,
                                e.blk_w.p, e.blk_s.p, cost_out);
         else
@@ -618,6 +838,55 @@ struct HipBackend final : Backend {
         hipLaunchKernelGGL(k_seg_sum, dim3(nblk(s.NACC, RS_COLS), s.n_cams), dim3(RS_COLS * RS_GROUPS), 0, e.stream, s.n_cams,
                            s.NACC, st.cam_seg.p, st.cam_partial.p, cam_out);
         if (!fused_cost) launch_cost(e, huber, cost_out);
+        CBA_HIP(hipGetLastError());
+    }
+    // ---- one linear solve's small stages in three launches (k_sys_stage2 / 3 / k_sys_pack above) -------------------------------------
+    bool vstats_pending = false;  // k_step_head has left the views' step statistics unreduced: stage 3 takes them along
+    double ctl_huber = 0.0;       // the Huber parameter of the running solve (the head of a step is queued without one at hand)
+    bool can_fuse() const { return st.fuse_small && st.schur_wave && st.s.n_views != 0 && !e.scalar; }
+    // Everything between Mode B and the exchange: [weights, cost, camera sums] (tail), the elimination of the views at private copy
+    // `which`, the contraction and the pack.  has_blocks / has_stats / has_cost: PackArgs.
+    void enqueue_system(double huber, bool tail, bool has_blocks, bool constrained, int which, const PackLayout& L, int has_stats, int has_cost = -1) {
+        const Structure& s = st.s;
+        const bool q2 = s.n_views != 0;
+        if (!can_fuse()) {
+            if (tail) enqueue_normal_eq_tail(huber, pack_target() + L.cam, st.stat_dev.p + 4);
+            if (q2) enqueue_schur(constrained, which, st.sys_tiles.p);
+            enqueue_pack(L, has_blocks, q2, has_stats, has_cost);
+            return;
+        }
+        const int n = s.nsh;
+        const int64_t sw = static_cast<int64_t>(st.n_pairs) * 4096;
+        if (tail && !e.head_weights)
+            hipLaunchKernelGGL(k_weights, dim3(nblk(s.n_blocks, 256)), dim3(256), 0, e.stream, s.n_blocks, s.NACC, s.NH + s.PL, e.blk_acc.p,
+                               huber, e.blk_w.p, e.blk_s.p);
+        SysArgs a{};
+        a.d = st.dims; a.n_views = s.n_views; a.n_blocks = s.n_blocks; a.nsh = n; a.n_tiles = st.n_tiles; a.n_pairs = st.n_pairs;
+        a.n_vchunks = st.n_vchunks; a.n_cams = s.n_cams; a.NACC = s.NACC; a.constrained = constrained ? 1 : 0;
+        a.n_cc = tail ? std::max(1, st.n_cchunks) : 0;
+        a.n_vb = static_cast<int>(nblk(s.n_views, 4));
+        a.n_costp = tail ? (s.n_blocks <= 4096 ? 1 : (s.n_blocks + 2047) / 2048) : 0;
+        a.n_seg_x = static_cast<int>(nblk(s.NACC, RS_COLS));
+        a.n_seg = tail ? a.n_seg_x * s.n_cams : 0;
+        a.n_syrk = st.n_vchunks * st.n_pairs;
+        a.has_vstats = vstats_pending ? 1 : 0;
+        a.huber = huber;
+        a.link_off = st.link_off.p; a.cchunk_off = st.cchunk_off.p; a.cam_seg = st.cam_seg.p;
+        a.link_blk = st.link_blk.p; a.cam_blk = st.cam_blk.p; a.view_fixed = e.view_fixed.p; a.view_cam_blk = st.view_cam_blk.p;
+        a.blk_acc = e.blk_acc.p; a.blk_w = e.blk_w.p; a.blk_s = e.blk_s.p; a.lmp = lmp_src; a.view = e.view[which].p;
+        a.view_scale2 = e.view_scale2.p; a.view_L = e.view_L.p; a.view_y = e.view_y.p; a.view_D = e.view_D.p; a.view_gp = e.view_gp.p;
+        a.blk_Z = e.blk_Z.p; a.view_gmax = st.view_gmax.p; a.cam_partial = st.cam_partial.p; a.cam_out = pack_target() + L.cam;
+        if (a.n_costp > 1 && e.cost_part.n < static_cast<size_t>(2 * a.n_costp)) e.cost_part.alloc(static_cast<size_t>(2 * a.n_costp));
+        a.cost_part = e.cost_part.p; a.cost_out = st.stat_dev.p + 4;
+        a.syrk_partial = st.syrk_partial.p; a.tiles_tail = st.sys_tiles.p + sw + n; a.view_stats = st.view_stats.p; a.stat_out = st.stat_dev.p;
+        hipLaunchKernelGGL(k_sys_stage2, dim3(a.n_cc + a.n_vb + a.n_costp), dim3(256), 0, e.stream, a);
+        const unsigned g3 = static_cast<unsigned>(a.n_seg + a.n_syrk + 1 + a.has_vstats + (a.n_costp > 1 ? 1 : 0));
+        if (n >= 64 && st.syrk_mfma) hipLaunchKernelGGL(k_sys_stage3<true>, dim3(g3), dim3(256), 0, e.stream, a);
+        else hipLaunchKernelGGL(k_sys_stage3<false>, dim3(g3), dim3(256), 0, e.stream, a);
+        vstats_pending = false;
+        hipLaunchKernelGGL(k_sys_pack, dim3(nblk(sw + n, RS_COLS)), dim3(RS_COLS * RS_GROUPS), 0, e.stream,
+                           pack_args(L, has_blocks, true, has_stats, has_cost), static_cast<int64_t>(st.n_vchunks), st.syrk_partial.p,
+                           st.sys_tiles.p + sw + n, st.stat_dev.p, pack_target());
         CBA_HIP(hipGetLastError());
     }
     void collect_normal_eq(std::vector<double>& cam_acc, double cost2[2]) {
@@ -799,9 +1068,10 @@ struct HipBackend final : Backend {
         const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
         st.pin_lmp.p[0] = radius;
         st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
-        if (q1) enqueue_normal_eq(huber, 0, pack_target() + L.cam, st.stat_dev.p + 4);
-        if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, q1, q2, 0);
+        (void)q2;
+        ctl_huber = huber;
+        if (q1) enqueue_normal_eq_head(0, huber);
+        enqueue_system(huber, q1, q1, constrained, 0, L, 0);
         exchange(L.cam, L.size - L.cam, ar, pack);
         e.active = 0;
     }
@@ -809,11 +1079,9 @@ struct HipBackend final : Backend {
         (void)rank;
         const Structure& s = st.s;
         ensure_pack(L);
-        const bool q2 = s.n_views != 0;
         st.pin_lmp.p[0] = radius;
         st.pin_lmp.p[1] = 0.0;
-        if (q2) enqueue_schur(constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, s.n_blocks != 0, q2, 0);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
+        enqueue_system(0.0, false, s.n_blocks != 0, constrained, 0, L, 0);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
         exchange(L.nfail, L.gmax - L.nfail, ar, pack);
     }
     bool sys_step(const double* delta_sh, double huber, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,
@@ -823,34 +1091,15 @@ struct HipBackend final : Backend {
         if (e.scalar) return false;  // fp32 study mode keeps the plain sequence
         ensure_pack(L);
         if (e.blk_acc_alt.n < e.blk_acc.n) { e.blk_acc_alt.alloc(e.blk_acc.n); e.blk_w_alt.alloc(e.blk_w.n); }
-        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
         std::memcpy(st.pin_pack[1].p + e.pk_delta, delta_sh, sizeof(double) * s.nsh);
         e.shared_pack[1].upload(st.pin_pack[1].p, e.pk_delta + static_cast<size_t>(s.nsh), e.stream);  // trial blocks + step
-        if (q2) {  // statistics of the step from the CURRENT factors, trial poses into copy 1
-            hipLaunchKernelGGL(st.schur_wave ? k_backsub_wave : k_backsub, st.schur_wave ? dim3(nblk(s.n_views, 4)) : dim3(nblk(s.n_views, 64)), st.schur_wave ? dim3(256) : dim3(64), 0, e.stream, st.dims, s.n_views, st.link_off.p,
-                               st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p,
-                               e.view_D.p, e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p, static_cast<const double*>(nullptr));
-            hipLaunchKernelGGL(k_col_reduce, dim3(1), dim3(256), 0, e.stream, s.n_views, 4, st.view_stats.p,
-                               static_cast<const double*>(nullptr), st.stat_dev.p);
-        } else {
-            CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
-        }
-        // linearise at the trial point into the second set of block sums / weights; the current set stays valid for a rejected step
+        // statistics of the step from the CURRENT factors, trial poses into copy 1; then the linearisation at the trial point into the
+        // second set of block sums / weights (the current set stays valid for a rejected step)
         st.pin_lmp.p[0] = radius_next;
         st.pin_lmp.p[1] = 0.0;
-        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-        std::swap(e.blk_w.p, e.blk_w_alt.p);
-        try {
-            if (q1) enqueue_normal_eq(huber, 1, pack_target() + L.cam, st.stat_dev.p + 4);
-            if (q2) enqueue_schur(constrained, 1, st.sys_tiles.p);
-        } catch (...) {
-            std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-            std::swap(e.blk_w.p, e.blk_w_alt.p);
-            throw;
-        }
-        std::swap(e.blk_acc.p, e.blk_acc_alt.p);
-        std::swap(e.blk_w.p, e.blk_w_alt.p);
-        enqueue_pack(L, q1, q2, 1);
+        ctl_huber = huber;
+        step_head_speculative();
+        step_tail_enqueue(huber, constrained, L);
         exchange(0, L.size, ar, pack);
         e.active = 1;
         return true;
@@ -995,9 +1244,10 @@ struct HipBackend final : Backend {
         (void)rank;
         const Structure& s = st.s;
         const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
-        if (q1) enqueue_normal_eq(huber, 0, pack_target() + L.cam, st.stat_dev.p + 4);
-        if (q2) enqueue_schur(ctl_constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, q1, q2, 0);
+        (void)q2;
+        ctl_huber = huber;
+        if (q1) enqueue_normal_eq_head(0, huber);
+        enqueue_system(huber, q1, q1, ctl_constrained, 0, L, 0);
         exchange(L.cam, L.size - L.cam, ar, nullptr, true);
         run_ctl(CTL_NEW, first ? 1 : 0);
         e.active = 0;
@@ -1005,9 +1255,7 @@ struct HipBackend final : Backend {
     void ctl_resolve(const PackLayout& L, const AllReduce& ar, int rank) override {
         (void)rank;
         const Structure& s = st.s;
-        const bool q2 = s.n_views != 0;
-        if (q2) enqueue_schur(ctl_constrained, 0, st.sys_tiles.p);
-        enqueue_pack(L, s.n_blocks != 0, q2, 0, 0);  // only [nfail .. g] travels
+        enqueue_system(0.0, false, s.n_blocks != 0, ctl_constrained, 0, L, 0, 0);  // only [nfail .. g] travels
         exchange(L.nfail, L.gmax - L.nfail, ar, nullptr, true);
         run_ctl(CTL_RESOLVED, 0);
     }
@@ -1025,27 +1273,44 @@ struct HipBackend final : Backend {
     void step_head_speculative() {
         const Structure& s = st.s;
         const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
-        if (q2) enqueue_backsub();
-        else CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        // one launch for the back-substitution and the block constants where a block's constants hang on its own view's pose
+        const bool fused_head = q1 && q2 && can_fuse() && e.chain != CBA_CHAIN_BUNDLE;
+        if (fused_head) {
+#define CBA_STEP_HEAD(CH)                                                                                                                  \
+    hipLaunchKernelGGL(k_step_head<CH>, dim3(nblk(s.n_views, 4)), dim3(256), 0, e.stream, e.gate, st.dims, s.n_views, st.link_off.p,         \
+                       st.link_blk.p, e.d_blk_cam.p, e.blk_Z.p, e.delta_sh.p, e.view_fixed.p, e.view_L.p, e.view_y.p, e.view_D.p,          \
+                       e.view_gp.p, e.view[0].p, st.view_delta.p, e.view[1].p, st.view_stats.p, e.cam[1].p, e.bc.p)
+            if (e.chain == CBA_CHAIN_INTRINSIC) CBA_STEP_HEAD(CH_INTRINSIC); else CBA_STEP_HEAD(CH_EXTRINSIC);
+#undef CBA_STEP_HEAD
+            launch_camera_consts(e, 1);
+            vstats_pending = true;
+        } else if (q2) {
+            enqueue_backsub();
+        } else {
+            CBA_HIP(hipMemsetAsync(st.stat_dev.p, 0, 4 * sizeof(double), e.stream));
+        }
         if (q1) {
             std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
             try {
-                enqueue_normal_eq_head(1);
+                enqueue_normal_eq_head(1, ctl_huber, fused_head);
             } catch (...) {
                 std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+                std::swap(e.blk_w.p, e.blk_w_alt.p);
                 throw;
             }
             std::swap(e.blk_acc.p, e.blk_acc_alt.p);
+            std::swap(e.blk_w.p, e.blk_w_alt.p);
         }
     }
-    void step_tail_speculative(double huber, const PackLayout& L, const AllReduce& ar) {
+    // ... and what follows Mode B, up to the assembled pack (the second set of block sums / weights, the trial poses)
+    void step_tail_enqueue(double huber, bool constrained, const PackLayout& L) {
         const Structure& s = st.s;
-        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        const bool q1 = s.n_blocks != 0;
         std::swap(e.blk_acc.p, e.blk_acc_alt.p);
         std::swap(e.blk_w.p, e.blk_w_alt.p);
         try {
-            if (q1) enqueue_normal_eq_tail(huber, pack_target() + L.cam, st.stat_dev.p + 4);
-            if (q2) enqueue_schur(ctl_constrained, 1, st.sys_tiles.p);  // with the radius the controller predicted
+            enqueue_system(huber, q1, q1, constrained, 1, L, 1);  // (the elimination with the radius the controller / the driver predicted)
         } catch (...) {
             std::swap(e.blk_acc.p, e.blk_acc_alt.p);
             std::swap(e.blk_w.p, e.blk_w_alt.p);
@@ -1053,7 +1318,9 @@ struct HipBackend final : Backend {
         }
         std::swap(e.blk_acc.p, e.blk_acc_alt.p);
         std::swap(e.blk_w.p, e.blk_w_alt.p);
-        enqueue_pack(L, q1, q2, 1);
+    }
+    void step_tail_speculative(double huber, const PackLayout& L, const AllReduce& ar) {
+        step_tail_enqueue(huber, ctl_constrained, L);
         exchange(0, L.size, ar, nullptr, true);
         run_ctl(CTL_STEP, 1);
         e.active = 1;
@@ -1063,6 +1330,7 @@ struct HipBackend final : Backend {
         const Structure& s = st.s;
         const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
         // the shared trial blocks and the shared step are where the controller left them (copy 1)
+        ctl_huber = huber;
         if (speculative) {
             step_head_speculative();
             step_tail_speculative(huber, L, ar);
@@ -1280,6 +1548,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     }
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_LM_FUSE")) st->fuse_small = std::atoi(env);
     if (const char* env = std::getenv("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);

@@ -222,6 +222,10 @@ struct Engine {
     int active = 0;  // parameter copy (0 current / 1 trial) the constants bc, sd were last built from
     const double* gate = nullptr;  // device flag the launches of block constants / Mode B check (0: do nothing); set by the LM driver
                                    // while it queues the head of a step ahead of the controller's decision, nullptr otherwise
+    // >= 0: launch_normal_eq() also leaves the blocks' robust weights / |r|^2 (blk_w, blk_s) for this Huber parameter where one
+    // of its kernels can take the work along; head_weights says whether the last call did (the caller skips k_weights then)
+    double head_huber = -1.0;
+    bool head_weights = false;
     DevBuf<int32_t> d_blk_cam, d_blk_view;
     DevBuf<Tile> tilesA, tilesB;
     DevBuf<int64_t> d_blk_tile_off;
@@ -262,6 +266,7 @@ struct Engine {
 // kernels_reproj.hip
 void ensure_f32_buffers(Engine& e);                      // fp32 copies of the observations + float tables
 void launch_block_consts(Engine& e, int which);         // params[which] -> bc, sd
+void launch_camera_consts(Engine& e, int which);        // ... the per-camera part alone (sd)
 void launch_eval(Engine& e);                            // Mode A: r, J at bc/sd
 void launch_resid(Engine& e);                           // Mode R: blk_s[b] = |r_b|^2
 void warm_reproj_kernels();                              // forces the code object of kernels_reproj.hip to load

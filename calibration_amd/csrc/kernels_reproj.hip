@@ -198,9 +198,11 @@ __global__ __launch_bounds__(256) void k_resid(const Tile* __restrict__ tiles, i
     if (lane == 63) partial_s[w] = s;
 }
 
-// out[b][e] = sum over the block's tiles (in tile order) of partial[t][e]
+// out[b][e] = sum over the block's tiles (in tile order) of partial[t][e].  s_idx >= 0: the rows are [H | g | s] rows and the thread
+// that finishes a block's s = |r|^2 also leaves the block's robust weight and s (k_weights' work, one launch less per LM step)
 __global__ void k_tile_sum(const double* __restrict__ gate, int n_blocks, int width, const int64_t* __restrict__ blk_tile_off,
-                           const double* __restrict__ partial, double* __restrict__ out) {
+                           const double* __restrict__ partial, double* __restrict__ out, int s_idx = -1, double huber_delta = 0.0,
+                           double* __restrict__ blk_w = nullptr, double* __restrict__ blk_s = nullptr) {
     if (gate && *gate == 0.0) return;
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= static_cast<int64_t>(n_blocks) * width) return;
@@ -209,6 +211,12 @@ __global__ void k_tile_sum(const double* __restrict__ gate, int n_blocks, int wi
     double s = 0.0;
     for (int64_t t = blk_tile_off[b]; t < blk_tile_off[b + 1]; ++t) s += partial[t * width + e];
     out[idx] = s;
+    if (e == s_idx) {
+        double rho, w;
+        huber(s, huber_delta, &rho, &w);
+        blk_w[b] = w;
+        blk_s[b] = s;
+    }
 }
 
 // scalar_out[0] = 1/2 sum_b rho(s_b), scalar_out[1] = sum_b s_b  (single workgroup, fixed order)
@@ -347,10 +355,14 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
     }
 }
 
-// blk_acc[b] = packed [H | g | s] of block b from its moment row; one wavefront per block, G and T = Qh Gh in LDS
+// blk_acc[b] = packed [H | g | s] of block b from its moment row; one wavefront per block, G and T = Qh Gh in LDS.
+// blk_tile_off != nullptr: `blk_mom` holds one row per TILE and the block's row is their sum in tile order (k_tile_sum's work and
+// order); blk_w != nullptr: the thread that forms s = |r|^2 also leaves the block's robust weight and s (k_weights' work) - two
+// launches less per LM step.
 template <int CHAIN, int PI>
 __global__ __launch_bounds__(64) void k_mom_expand(const double* __restrict__ gate, int n_blocks, const double* __restrict__ bc, const double* __restrict__ blk_mom,
-                                                   double* __restrict__ blk_acc) {
+                                                   double* __restrict__ blk_acc, const int64_t* __restrict__ blk_tile_off = nullptr,
+                                                   double huber_delta = 0.0, double* __restrict__ blk_w = nullptr, double* __restrict__ blk_s = nullptr) {
     if (gate && *gate == 0.0) return;
     constexpr int PL = 12 + PI, NH = PL * (PL + 1) / 2, NACC = NH + PL + 1, NMOM = MomLayout<PI>::N;
     static constexpr UpperIndex<PL> UI{};
@@ -360,13 +372,29 @@ __global__ __launch_bounds__(64) void k_mom_expand(const double* __restrict__ ga
     const int b = blockIdx.x;
     if (b >= n_blocks) return;
     if (threadIdx.x < 3) pose_affine_G_part<CHAIN>(bc + static_cast<int64_t>(b) * BC_SIZE, threadIdx.x, G[threadIdx.x]);
-    for (int e = threadIdx.x; e < NMOM; e += 64) mom[e] = blk_mom[static_cast<int64_t>(b) * NMOM + e];
+    if (blk_tile_off) {
+        const int64_t t0 = blk_tile_off[b], t1 = blk_tile_off[b + 1];
+        for (int e = threadIdx.x; e < NMOM; e += 64) {
+            double s = 0.0;
+            for (int64_t t = t0; t < t1; ++t) s += blk_mom[t * NMOM + e];
+            mom[e] = s;
+        }
+    } else {
+        for (int e = threadIdx.x; e < NMOM; e += 64) mom[e] = blk_mom[static_cast<int64_t>(b) * NMOM + e];
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < 9 * 12; e += 64) T[e] = mom_expand_T<PI>(mom, G, e / 12, e % 12);
     __syncthreads();
     for (int e = threadIdx.x; e < NACC; e += 64) {
         const int i = e < NH ? UI.i[e] : 0, j = e < NH ? UI.j[e] : 0;
-        blk_acc[static_cast<int64_t>(b) * NACC + e] = mom_expand_entry_T<PI>(mom, G, T, e, i, j);
+        const double val = mom_expand_entry_T<PI>(mom, G, T, e, i, j);
+        blk_acc[static_cast<int64_t>(b) * NACC + e] = val;
+        if (e == NACC - 1 && blk_w) {
+            double rho, w;
+            huber(val, huber_delta, &rho, &w);
+            blk_w[b] = w;
+            blk_s[b] = val;
+        }
     }
 }
 
@@ -432,6 +460,15 @@ void launch_block_consts(Engine& e, int which) {
     if (e.scalar)
         hipLaunchKernelGGL(k_to_f32, dim3(blocks_for(static_cast<int64_t>(e.n_cams) * e.PI, 64)), dim3(64), 0, e.stream,
                            static_cast<int64_t>(e.n_cams) * e.PI, e.intr[which].p, e.intrf.p);
+    CBA_HIP(hipGetLastError());
+}
+
+// the per-camera part of launch_block_consts alone (the caller has built the block constants itself: backend_hip.hip k_step_head)
+void launch_camera_consts(Engine& e, int which) {
+    e.active = which;
+    if (e.model == CAM_SCHEIMPFLUG)
+        hipLaunchKernelGGL(k_scheimpflug_consts, dim3(blocks_for(e.n_cams, 64)), dim3(64), 0, e.stream, e.gate, e.n_cams,
+                           e.intr[which].p, e.sd.p, static_cast<float*>(nullptr));
     CBA_HIP(hipGetLastError());
 }
 
@@ -585,7 +622,6 @@ static void launch_mom_part(Engine& e, unsigned g) {
 template <int C, int M>
 static void launch_mom(Engine& e, unsigned g) {
     constexpr int PI = IntrSize<M>::value;
-    constexpr int NMOM = MomLayout<PI>::N;
     if (e.modeb_shared && launch_normal_eq_shared_rows(e, one_tile_per_block(e) ? e.blk_mom.p : e.partial.p)) {
         // one workgroup of 3 / 4 wavefronts per tile, rows evaluated once (kernels_modeb.hip)
     } else if constexpr (M == CAM_PINHOLE_BC) {  // 201 sums -> 3 parts of 67
@@ -593,14 +629,17 @@ static void launch_mom(Engine& e, unsigned g) {
     } else {                    // 244 sums -> 4 parts of 61
         launch_mom_part<M, 4, 0>(e, g); launch_mom_part<M, 4, 1>(e, g); launch_mom_part<M, 4, 2>(e, g); launch_mom_part<M, 4, 3>(e, g);
     }
-    const int64_t tot = static_cast<int64_t>(e.n_blocks) * NMOM;
-    if (!one_tile_per_block(e))
-        hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.gate, e.n_blocks, NMOM, e.d_blk_tile_off.p, e.partial.p,
-                           e.blk_mom.p);
-    hipLaunchKernelGGL((k_mom_expand<C, PI>), dim3(e.n_blocks), dim3(64), 0, e.stream, e.gate, e.n_blocks, e.bc.p, e.blk_mom.p, e.blk_acc.p);
+    // the tile sum and (when the caller gave a Huber parameter, Engine::head_huber) the block weights ride in the expansion
+    const bool w = e.head_huber >= 0.0;
+    const bool tiles = !one_tile_per_block(e);
+    hipLaunchKernelGGL((k_mom_expand<C, PI>), dim3(e.n_blocks), dim3(64), 0, e.stream, e.gate, e.n_blocks, e.bc.p, tiles ? e.partial.p : e.blk_mom.p,
+                       e.blk_acc.p, tiles ? e.d_blk_tile_off.p : static_cast<const int64_t*>(nullptr), e.head_huber, w ? e.blk_w.p : static_cast<double*>(nullptr),
+                       w ? e.blk_s.p : static_cast<double*>(nullptr));
+    e.head_weights = w;
 }
 
 void launch_normal_eq(Engine& e) {
+    e.head_weights = false;
     if (e.n_tilesB == 0) return;
     const unsigned g = blocks_for(e.n_tilesB, 4);
     if (e.chain != CH_INTRINSIC && e.modeb_moments) {
@@ -613,9 +652,12 @@ void launch_normal_eq(Engine& e) {
     CBA_DISPATCH(e, CALL)
 #undef CALL
     const int64_t tot = static_cast<int64_t>(e.n_blocks) * e.NACC;
-    if (!one_tile_per_block(e))
+    if (!one_tile_per_block(e)) {
+        const bool w = e.head_huber >= 0.0;
         hipLaunchKernelGGL(k_tile_sum, dim3(blocks_for(tot, 256)), dim3(256), 0, e.stream, e.gate, e.n_blocks, e.NACC,
-                           e.d_blk_tile_off.p, e.partial.p, e.blk_acc.p);
+                           e.d_blk_tile_off.p, e.partial.p, e.blk_acc.p, w ? e.NACC - 1 : -1, e.head_huber, e.blk_w.p, e.blk_s.p);
+        e.head_weights = w;
+    }
     CBA_HIP(hipGetLastError());
 }
 

@@ -47,6 +47,24 @@ struct BlockTeam {
         __syncthreads();
         return m;
     }
+    // exclusive prefix count of a flag over the team in thread order (ballot inside the wavefront, the wavefronts' totals through LDS)
+    __device__ __forceinline__ int count_before(bool flag, int* total) const {
+        const unsigned long long mask = __ballot(flag);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) red[wave] = static_cast<double>(__popcll(mask));
+        __syncthreads();
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < CTL_WAVES; ++w) {
+            const int cw = static_cast<int>(red[w]);
+            base += w < wave ? cw : 0;
+            tot += cw;
+        }
+        __syncthreads();
+        *total = tot;
+        return base + before;
+    }
     __device__ __forceinline__ void mark(int) const {}
     // time since the previous tick -> the phase's slot (thread 0; 100 MHz constant clock)
     __device__ __forceinline__ void tick(const CtlView& V, int slot) const {

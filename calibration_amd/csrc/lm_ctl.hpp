@@ -105,6 +105,8 @@ struct SerialTeam {
     CBA_HD void sync() const {}
     CBA_HD double sum(double v) const { return v; }
     CBA_HD double max(double v) const { return v; }
+    // number of threads before this one (in thread order) whose flag is set, and the team's total
+    CBA_HD int count_before(bool flag, int* total) const { *total = flag ? 1 : 0; return 0; }
     CBA_HD void tick(const CtlView&, int) const {}
     CBA_HD void mark(int) const {}
     CBA_HD void publish(const CtlView& V) const {
@@ -247,10 +249,16 @@ CBA_HD void ctl_adopt(TM& tm, const CtlView& V, bool init_scale) {
         }
     }
     tm.sync();
+    int m = 0;  // the effective columns in order: a prefix count over the team per chunk of columns (not one thread walking all n)
+    for (int base = 0; base < n; base += tm.size()) {
+        const int i = base + tm.tid();
+        const bool on = i < n && V.eff[i];
+        int tot;
+        const int before = tm.count_before(on, &tot);
+        if (on) V.idx[m + before] = i;
+        m += tot;
+    }
     if (tm.tid() == 0) {
-        int m = 0;
-        for (int i = 0; i < n; ++i)
-            if (V.eff[i]) V.idx[m++] = i;
         V.scal[CS_M] = m;
         V.scal[CS_COST] = V.pack[V.off_cost];
         V.scal[CS_NFAIL] = floor(V.pack[V.off_nfail] + 0.5);
@@ -318,23 +326,22 @@ CBA_HD bool ctl_cholesky(TM& tm, double* A, int lda, int M, double* Ld, double* 
                 for (int j = 0; j <= i; ++j) L[i][j] = Dg[i * lda + j];
             bool ok = true;
             tm.mark(1);
+            // right-looking inside the block: once column j is final, every later entry takes its update at once (independent
+            // multiply-adds; the left-looking form is one dependent chain per entry) - the same subtractions in the same order
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                double d = L[j][j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+                const double d = L[j][j];
                 if (!(d > 0.0) || !ctl_finite(d)) ok = false;
                 double sq, r;
                 ctl_sqrt_rsqrt(d, &sq, &r);
                 inv[j] = r;
                 L[j][j] = sq;
 #pragma unroll
-                for (int i = j + 1; i < NB; ++i) {
-                    double s = L[i][j];
+                for (int i = j + 1; i < NB; ++i) L[i][j] *= r;
 #pragma unroll
-                    for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-                    L[i][j] = s * r;
-                }
+                for (int i = j + 1; i < NB; ++i)
+#pragma unroll
+                    for (int c = j + 1; c <= i; ++c) L[i][c] -= L[i][j] * L[c][j];
             }
             if (tm.tid() == 0) {
                 *okflag = ok ? 1 : 0;
@@ -349,10 +356,9 @@ CBA_HD bool ctl_cholesky(TM& tm, double* A, int lda, int M, double* Ld, double* 
                 for (int c = 0; c < NB; ++c) x[c] = row[c];
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    double sacc = x[c];
+                    x[c] *= inv[c];
 #pragma unroll
-                    for (int k = 0; k < c; ++k) sacc -= x[k] * L[c][k];
-                    x[c] = sacc * inv[c];
+                    for (int k = c + 1; k < NB; ++k) x[k] -= x[c] * L[k][c];
                 }
                 double* dst = i < b0 ? Ld + (p * NB + (i - k0)) * NB : row;  // a row of the diagonal block is its row of L
 #pragma unroll
@@ -486,32 +492,29 @@ CBA_HD bool ctl_solve(TM& tm, const CtlView& V, double radius) {
     const double* S = V.pack + V.off_S;
     const double* gs = V.pack + V.off_g;
     const int M = (m + CTL_NB - 1) / CTL_NB * CTL_NB;  // padded with identity rows: every panel is full, no guards in the factorisation
-    // rows r of the lower triangle, columns dealt to the threads of a row group: thread t handles rows t / RT, t / RT + RG, ..., of
-    // each the columns t % RT, t % RT + RT, ...  (independent loads, unrolled so that several are in flight)
+    // the lower triangle element by element (e -> (r, c) by the triangular root), then the right-hand-side row: independent loads,
+    // unrolled so that many are in flight at once (the pack and the camera sums sit in L2: ~1 us per dependent round trip)
     {
-        const int RT = 16, RG = tm.size() >= RT ? tm.size() / RT : 1, cl = tm.size() >= RT ? tm.tid() % RT : 0, rg = tm.size() >= RT ? tm.tid() / RT : 0;
-        const int cstep = tm.size() >= RT ? RT : 1;
-        for (int r = rg; r <= M; r += RG) {
-            double* Arow = V.A + r * V.lda;
+        const int tot = M * (M + 1) / 2;
+#pragma unroll 8
+        for (int e0 = tm.tid(); e0 < tot; e0 += tm.size()) {
+            int r = static_cast<int>((sqrtf(8.0f * static_cast<float>(e0) + 1.0f) - 1.0f) * 0.5f);
+            r += ((r + 1) * (r + 2) / 2 <= e0) ? 1 : 0;
+            r -= (r * (r + 1) / 2 > e0) ? 1 : 0;
+            const int c = e0 - r * (r + 1) / 2;
+            double val = r == c ? 1.0 : 0.0;  // the identity padding
             if (r < m) {
-                const int i = V.idx[r];
-#pragma unroll 4
-                for (int c = cl; c <= r; c += cstep) {
-                    const int j = V.idx[c];
-                    double val = ctl_hcc(V, V.camc, i, j) - S[ctl_sidx(n, i, j)];
-                    if (r == c) val += lm_diag(V.hdiag[i], V.scale2[i], radius);
-                    Arow[c] = val;
-                }
-            } else if (r < M) {
-                for (int c = cl; c <= r; c += cstep) Arow[c] = r == c ? 1.0 : 0.0;
-            } else {
-#pragma unroll 4
-                for (int c = cl; c < M; c += cstep) {
-                    const int i = V.idx[c < m ? c : 0];
-                    const double b = -(V.gc[i] - gs[i]);
-                    Arow[c] = c < m ? b : 0.0;
-                }
+                const int i = V.idx[r], j = V.idx[c];
+                val = ctl_hcc(V, V.camc, i, j) - S[ctl_sidx(n, i, j)];
+                if (r == c) val += lm_diag(V.hdiag[i], V.scale2[i], radius);
             }
+            V.A[r * V.lda + c] = val;
+        }
+        double* Arow = V.A + M * V.lda;
+        for (int c = tm.tid(); c < M; c += tm.size()) {
+            const int i = V.idx[c < m ? c : 0];
+            const double b = -(V.gc[i] - gs[i]);
+            Arow[c] = c < m ? b : 0.0;
         }
     }
     tm.sync();

@@ -11,6 +11,8 @@ struct HipLMState {
     Structure s;
     SchurDims dims;
     int n_vchunks = 0, n_tiles = 0, n_pairs = 0, n_cchunks = 0;
+    int fuse_small = 1; // the small stages of a linear solve share launches (backend_hip.hip k_sys_stage2 / 3 / k_sys_pack / k_step_head);
+                        // 0: one launch per stage (experiment builds: CBA_LM_FUSE)
     int schur_wave = 1; // per-view elimination / back-substitution with one wavefront per view (0: one thread per view, CBA_SCHUR_WAVE)
     int syrk_mfma = 1;  // Schur contraction on the matrix cores when nsh >= 64 (CBA_SYRK_MFMA=0: register-blocked VALU form)
     DevBuf<int32_t> view_cam_blk, cam_blk;
