@@ -181,9 +181,17 @@ def main():
             h.set_params(intr=init_intr, view_pose=init_view)
             s, lm_s = timed_solve(h)
             xs = h.solve_stats()
-            lm_box["lm"] = {"wall_s": lm_s, "iterations": int(s.iterations), "success": bool(s.success),
+            flat_result = flat.intr.copy()
+            ab = None
+            if world == 1:  # A/B (one rank only): the same iteration with the reduced solve and the step decision on the HOST
+                h.set_lm_mode(3)  # (cba_reproj_set_lm_mode 3: diagnostic form; the default keeps them on the device, lm_ctl.hip)
+                h.set_params(intr=init_intr, view_pose=init_view)
+                s_ab, ab = timed_solve(h)
+                h.set_lm_mode(1)
+                ab = {"wall_s": ab, "iterations": int(s_ab.iterations)}
+            lm_box["lm"] = {"wall_s": lm_s, "host_side_form": ab, "iterations": int(s.iterations), "success": bool(s.success),
                             "final_cost": float(s.final_cost),
-                            "intr_err_max": float(np.abs(flat.intr - scene.gt_intr).max()), "views_total": world * args.views,
+                            "intr_err_max": float(np.abs(flat_result - scene.gt_intr).max()), "views_total": world * args.views,
                             "obs_total": world * n_obs, "allreduce": transport, "allreduce_calls": xs["allreduce_calls"],
                             "allreduce_bytes": 8 * xs["allreduce_doubles"], "accepted_steps": int(s.successful_steps),
                             "speculation": {k: xs[k] for k in ("speculative_steps", "speculation_hits", "speculation_misses", "rejected_steps")}}
@@ -206,11 +214,18 @@ def main():
                 h3.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
                 s3, wall3b = timed_solve(h3)
                 xs3 = h3.solve_stats()
+                ab3 = None
+                if world == 1:  # A/B as above
+                    h3.set_lm_mode(3)
+                    h3.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
+                    s_ab3, ab3 = timed_solve(h3)
+                    h3.set_lm_mode(1)
+                    ab3 = {"wall_s": ab3, "iterations": int(s_ab3.iterations)}
                 ms_b3 = h3.normal_eq_timed(1, 3)
             obs_total = args.c3_views * 8 * 5000
             lm_box["lm_strong"] = {"workload": f"8-camera extrinsic bundle, {args.c3_views} views x 8 cameras x 5000 pts = {obs_total:.3g} observations "
                                                f"in total, views split over {world} rank(s) (BASELINE configs[2])",
-                                   "scaling": "strong", "wall_s": min(wall3, wall3b), "wall_first_s": wall3, "iterations": int(s3.iterations),
+                                   "scaling": "strong", "wall_s": min(wall3, wall3b), "wall_first_s": wall3, "host_side_form": ab3, "iterations": int(s3.iterations),
                                    "accepted_steps": int(s3.successful_steps), "success": bool(s3.success), "final_cost": float(s3.final_cost),
                                    "intr_err_max": float(np.abs(sc3.flat.intr - sc3.gt_intr)[:, :4].max()), "allreduce": transport3,
                                    "allreduce_calls": xs3["allreduce_calls"], "allreduce_bytes": 8 * xs3["allreduce_doubles"],

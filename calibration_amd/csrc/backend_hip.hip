@@ -1549,7 +1549,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_LM_FUSE")) st->fuse_small = std::atoi(env);
-    if (const char* env = std::getenv("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);
         st->graphs_ok = v != 0;
@@ -1573,9 +1573,9 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     st->res_Hcc.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_Ssch.alloc(static_cast<size_t>(s.nsh) * s.nsh);
     st->res_out.alloc(32);
-    if (const char* env = std::getenv("CBA_LM_CTL")) st->lm_ctl_mode = std::atoi(env) != 0;
-    if (const char* env = std::getenv("CBA_LM_CTL_POLL_US")) st->ctl_poll_us = std::atoi(env);
-    if (const char* env = std::getenv("CBA_LM_PRELAUNCH")) st->ctl_prelaunch = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_LM_CTL")) st->lm_ctl_mode = std::atoi(env) != 0;
+    if (const char* env = cba_exp_env("CBA_LM_CTL_POLL_US")) st->ctl_poll_us = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_LM_PRELAUNCH")) st->ctl_prelaunch = std::atoi(env);
     if (const char* env = std::getenv("CBA_RCCL_TIMEOUT_S")) st->rccl_timeout_s = std::max(1, std::atoi(env));
     warm_lm_ctl();
     if (const char* env = std::getenv("CBA_LM_RESIDENT")) st->resident_mode = std::atoi(env);

@@ -20,6 +20,7 @@
 //   partial           [n_tilesB][NACC]  per-tile Mode B sums;  blk_acc [n_blocks][NACC] per-block sums
 #pragma once
 #include <hip/hip_runtime.h>
+#include "exp_env.hpp"
 
 #include <cstdint>
 #include <deque>
@@ -45,14 +46,6 @@ struct NoDevice : std::runtime_error {
 // through the environment - part counts, layouts, timing-only ablations whose results are WRONG - is an experiment knob: read
 // through cba_exp_env(), which answers only in a library built with -DCBA_EXPERIMENTS (make EXPERIMENTS=1; tools/exp.py uses such
 // a build).  In the shipped library a stray variable in a user's environment cannot change what a calibration computes.
-inline const char* cba_exp_env(const char* name) {
-#ifdef CBA_EXPERIMENTS
-    return std::getenv(name);
-#else
-    (void)name;
-    return nullptr;
-#endif
-}
 
 #define CBA_HIP(expr)                                                                                      \
     do {                                                                                                   \

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "dense.hpp"
+#include "exp_env.hpp"
 #include "line_search.hpp"
 #include "lm_ctl.hpp"
 #include "reproj_math.hpp"
@@ -214,9 +215,9 @@ class LMDriver {
         pack_.assign(static_cast<size_t>(L_.size), 0.0);
         if (const char* env = std::getenv("CBA_LM_SPECULATE")) speculate_ = std::atoi(env) != 0;
         if (const char* env = std::getenv("CBA_LM_LINE_SEARCH")) line_search_ = std::atoi(env) != 0;
-        if (const char* env = std::getenv("CBA_LM_CTL")) use_ctl_ = std::atoi(env) != 0;
-        if (const char* env = std::getenv("CBA_LM_PIPELINE")) pipeline_ = std::atoi(env) != 0;
-        if (const char* env = std::getenv("CBA_LM_PRELAUNCH")) prelaunch_ = std::atoi(env) != 0;
+        if (const char* env = cba_exp_env("CBA_LM_CTL")) use_ctl_ = std::atoi(env) != 0;
+        if (const char* env = cba_exp_env("CBA_LM_PIPELINE")) pipeline_ = std::atoi(env) != 0;
+        if (const char* env = cba_exp_env("CBA_LM_PRELAUNCH")) prelaunch_ = std::atoi(env) != 0;
     }
     LMDriver(const LMDriver&) = delete;  // ar_ captures `this`
     LMDriver& operator=(const LMDriver&) = delete;

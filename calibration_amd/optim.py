@@ -399,8 +399,8 @@ class ReprojHandle:
         return out
 
     def set_lm_mode(self, mode: int):
-        """0 = host-driven LM iteration, 1 = automatic (default), 2 = the resident single-launch kernel whenever it can
-        take the problem (cba_reproj_set_lm_mode)."""
+        """0 = staged LM iteration (device controller), 1 = automatic (default), 2 = the resident single-launch kernel whenever it
+        can take the problem, 3 = staged with the reduced solve and step decision on the host (diagnostic A/B); cba_reproj_set_lm_mode."""
         capi.check(self.lib, self.lib.cba_reproj_set_lm_mode(self.h, int(mode)))
 
     def solve_stats(self) -> dict:

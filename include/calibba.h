@@ -222,14 +222,17 @@ int64_t cba_reproj_block_normal_eq_size(const cba_reproj* h); /* doubles per blo
 /* Levenberg-Marquardt solve (what solve_problem + ceres::Solve do, ceresutils.h:27-43). */
 cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary* summary);
 
-/* How cba_reproj_solve runs the iteration.  0: host-driven (every stage a kernel launch, the accept / reject loop on the host;
- * the only form for multi-rank handles, verbose solves and the fp32 study).  2: "resident" — the whole solve in ONE launch of a
- * single-workgroup kernel, for problems too small to fill the chip (the sizes the reference's own tests and pipelines run:
- * the host-driven iteration costs ~0.09 ms per LM step however little work it carries); falls back to 0 when the kernel cannot
- * take the problem (reduced system wider than 80, > 16 cameras).  1 (default): resident below the measured crossover with
- * the host-driven form (intrinsic chain: 1.2 n_views + 0.0105 n_obs <= 48, e.g. 20 views x 88 points; the host-driven
- * iteration runs a step in ~86 us and wins on the two-pose chains at every size).
- * Both forms follow the same rules and agree to rounding. */
+/* How cba_reproj_solve runs the iteration.  0: stage by stage (every stage a kernel launch on the handle's stream; the only form
+ * for multi-rank handles, verbose solves and the fp32 study).  The reduced system, the step decision, the radius update and the
+ * next trial point of the shared blocks are the work of ONE single-workgroup controller kernel right behind the packed exchange
+ * (csrc/lm_ctl.hip): the host queues launch sequences and reads a control record, it takes no part in the arithmetic.
+ * 2: "resident" - the whole solve in ONE launch of a single-workgroup kernel, for problems too small to fill the chip (the
+ * sizes the reference's own tests and pipelines run); falls back to 0 when the kernel cannot take the problem (reduced system
+ * wider than 80, > 16 cameras, a transport set).  1 (default): resident below the measured crossover with the staged form
+ * (intrinsic chain: 1.2 n_views + 0.0105 n_obs <= 48, e.g. 20 views x 88 points), staged otherwise.
+ * 3 (diagnostic, for A/B measurements): as 0, but the reduced solve and the step decision run on the host from a copy of the
+ * reduced pack, as they did before the controller existed.
+ * All forms follow the same rules, take the same decisions and agree to rounding. */
 cba_status cba_reproj_set_lm_mode(cba_reproj* h, int32_t mode);
 
 /* What the last host-driven cba_reproj_solve on this handle exchanged between ranks (one packed

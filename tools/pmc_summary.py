@@ -30,6 +30,6 @@ out = {
     "read_bytes_per_launch": 2 * fetch * 1024, "write_bytes_per_launch": write * 1024,
     "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024, "algorithmic_bytes_per_launch": 304 * 10_000_000,
 }
-for name in ("pmc_k_eval.json", sys.argv[1] if len(sys.argv) > 1 else "r01_pmc_k_eval_latest.json"):
+for name in ("pmc_k_eval.json", sys.argv[1] if len(sys.argv) > 1 else "r03_pmc_k_eval.json"):
     json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out))
