@@ -499,6 +499,25 @@ int hm_reproj_solve(const cba_reproj_problem* d, const cba_options* o, cba_allre
     return hm_reproj_solve_ex(d, o, fn, user, n_ranks, rank, -1, out, nullptr);
 }
 
+// The controller's reduced solve alone (lm_ctl.hpp ctl_cholesky + ctl_backsolve, one-thread team): x = A^-1 b for the symmetric
+// n x n matrix A (row-major; the lower triangle is read).  Returns 1 when a pivot is not positive.
+int hm_ctl_dense_solve(int n, const double* A, const double* b, double* x) {
+    int bad = 0;
+    const int rc = guarded([&] {
+        const int M = ctl_padded(n), lda = ctl_lda(n);
+        std::vector<double> W(static_cast<size_t>(M + 1) * lda, 0.0), Ld(static_cast<size_t>(M) * CTL_NB, 0.0), rd(M, 0.0), xs(M, 0.0);
+        for (int r = 0; r < M; ++r)
+            for (int c = 0; c <= r; ++c) W[static_cast<size_t>(r) * lda + c] = r < n ? A[static_cast<size_t>(r) * n + c] : (r == c ? 1.0 : 0.0);
+        for (int c = 0; c < n; ++c) W[static_cast<size_t>(M) * lda + c] = b[c];
+        SerialTeam tm;
+        int ok = 1;
+        if (!ctl_cholesky(tm, W.data(), lda, M, Ld.data(), rd.data(), &ok)) { bad = 1; return; }
+        ctl_backsolve(tm, W.data(), lda, M, Ld.data(), rd.data(), xs.data());
+        for (int c = 0; c < n; ++c) x[c] = xs[c];
+    });
+    return rc != 0 ? rc : bad;
+}
+
 // per-block packed [H | g | s] rows at the problem's parameters, through the direct (moments = 0) or the moment form
 int hm_reproj_block_normal_eq(const cba_reproj_problem* d, int moments, double* out) {
     return guarded([&] {

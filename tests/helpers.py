@@ -63,6 +63,7 @@ def load_hostmath():
     h.hm_reproj_eval.argtypes = [PP, c_double_p, c_double_p]
     h.hm_reproj_solve.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, PS]
     h.hm_reproj_solve_ex.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_int, PS, C.POINTER(C.c_int64)]  # stats8
+    h.hm_reproj_solve_mode.argtypes = [PP, PO, capi.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, PS, C.POINTER(C.c_int64)]
     h.hm_reproj_block_normal_eq.argtypes = [PP, C.c_int, c_double_p]
     h.hm_structure_check.argtypes = [PP, C.c_int]
     h.hm_reproj_masks.argtypes = [PP, PO, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]

@@ -224,6 +224,72 @@ def test_speculative_steps_take_the_same_decisions_as_the_two_exchange_sequence(
     assert calls < xa[0] and xa[7] == ls_evals
 
 
+def hm_solve_mode(hostmath, flat, o, controller, speculate=-1):
+    d = flat.struct()
+    s = CbaSummary()
+    xs = (C.c_int64 * 8)()
+    st = hostmath.hm_reproj_solve_mode(C.byref(d), C.byref(o), capi.ALLREDUCE_FN(), None, 1, 0, speculate, controller, C.byref(s), xs)
+    assert st == 0, hostmath.hm_last_error()
+    return s, [int(v) for v in xs]
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 10, 15, 16, 17, 31, 64, 100, 120, 127, 128, 129, 137, 200])
+def test_controller_reduced_solve_against_numpy(hostmath, n):
+    """The blocked right-looking Cholesky + back-substitution of the LM controller (lm_ctl.hpp: panels of 8, identity padding to a
+    multiple of 8, the right-hand side carried as an extra row, diagonal-block factors stored apart) on random SPD systems of every
+    residue mod 8 and on both sides of the 128-wide LDS limit; and that a non-positive pivot is reported, not factorised."""
+    rng = np.random.default_rng(n)
+    Bm = rng.normal(size=(n + 3, n))
+    A = Bm.T @ Bm + 0.1 * np.eye(n)
+    b = rng.normal(size=n)
+    x = np.zeros(n)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    hostmath.hm_ctl_dense_solve.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    assert hostmath.hm_ctl_dense_solve(n, dp(A), dp(b), dp(x)) == 0, hostmath.hm_last_error()
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()) * np.linalg.cond(A) ** 0.5
+    A2 = A.copy()
+    A2[n // 2, n // 2] = -1.0
+    assert hostmath.hm_ctl_dense_solve(n, dp(A2), dp(b), dp(x)) == 1
+
+
+CTL_CASES = [("intr", 0, 0.2, {}, False), ("intr", 1, 0.2, {}, False), ("intr", 0, 0.2, dict(optimize_skew=1, huber_delta=0.2), False),
+             ("ext", 0, 0.2, {}, False), ("ext", 1, 0.0, dict(optimize_intrinsics=0), False), ("ext", 0, 0.2, dict(optimize_extrinsics=0), False),
+             ("bundle", 0, 0.2, dict(optimize_intrinsics=1), False), ("bundle", 0, 0.2, dict(optimize_intrinsics=0, optimize_target_pose=0), False),
+             ("bundle", 1, 0.0, dict(optimize_intrinsics=1), False),
+             ("intr", 0, 7, {}, True), ("ext", 0, 9, {}, True), ("intr", 0, 19, {}, True), ("ext", 0, 23, {}, True)]
+
+
+@pytest.mark.parametrize("kind,model,noise_or_seed,okw,rough", CTL_CASES)
+@pytest.mark.parametrize("speculate", [1, 0])
+def test_controller_takes_the_decisions_of_the_host_side_form(hostmath, kind, model, noise_or_seed, okw, rough, speculate):
+    """lm_ctl.hpp (what libcalibba runs as ONE workgroup behind every exchange: gain ratio, accept / reject, radius, convergence
+    tests, adoption, the reduced system's blocked Cholesky, Plus on the shared blocks, the projected line search's bookkeeping)
+    against LMDriver::solve_host, the host-side form it replaced (dense.hpp) - here both on the CPU backend, the controller through
+    its one-thread team.  Same termination, iteration / accepted-step counts and exchange statistics (speculative hits, radius
+    misses, rejections, line searches and their samples); cost and parameters equal to rounding (the two factorisations add in
+    different orders).  Rough starts (rejected steps, line searches on the fx, fy >= 0 bound) included.
+    ceres::Solve's loop: src/estimation/detail/ceresutils.h:27-43."""
+    if rough:
+        a, b = helpers.rough_start_scene(kind, model, noise_or_seed), helpers.rough_start_scene(kind, model, noise_or_seed)
+        o = options(epsilon=1e-10)
+    else:
+        mk = {"intr": lambda: synth.scene_intrinsics(10, model=model, spacing=0.08, noise_px=noise_or_seed),
+              "ext": lambda: synth.scene_extrinsics(6, 3, model=model, spacing=0.08, noise_px=noise_or_seed),
+              "bundle": lambda: synth.scene_bundle(12, 2, model=model, spacing=0.04, noise_px=noise_or_seed)}[kind]
+        a, b = mk(), mk()
+        o = options(epsilon=1e-12, **okw)
+    sa, xa = hm_solve_mode(hostmath, a.flat, o, 0, speculate)
+    sb, xb = hm_solve_mode(hostmath, b.flat, o, 1, speculate)
+    assert (sb.termination, sb.iterations, sb.successful_steps) == (sa.termination, sa.iterations, sa.successful_steps), (sa.report, sb.report)
+    assert sb.report.split(b" cost ")[0] == sa.report.split(b" cost ")[0]  # (message and iteration count; the costs follow below)
+    assert xb[0] == xa[0] and xb[2:] == xa[2:], (xa, xb)  # (the doubles exchanged differ by a few: which slice of the pack a plain trial sends)
+    if rough:
+        assert xa[5] + xa[6] >= 1  # the case does exercise rejections / line searches
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-11 * max(1.0, sa.final_cost) + 1e-20
+    assert helpers.param_diff(a.flat, b.flat) <= (1e-7 if model == 1 else 1e-8 if rough else 1e-10)  # (rough starts stop at epsilon 1e-10)
+
+
 @pytest.mark.parametrize("seed", [3, 5])
 def test_scheimpflug_well_conditioned_scene_meets_the_1e9_bar(oracle, hostmath, seed):
     """Scheimpflug parity at the north-star's bar.  On a scene whose data determine every parameter (large board, tilts up to 45
