@@ -205,6 +205,18 @@ PROTOTYPES = {
         [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
          c_int32_p, c_double_p, C.c_int32, C.POINTER(CbaOptions), C.POINTER(CbaSummary), c_double_p, c_double_p, c_double_p],
     ),
+    "cba_optimize_intrinsics_semidlt_sharded": (
+        C.c_int32,
+        [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32,
+         c_double_p, c_double_p, c_int32_p, c_double_p, C.c_int32, C.POINTER(CbaOptions), C.POINTER(CbaSummary), c_double_p, c_double_p,
+         c_double_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32, C.c_int32],
+    ),
+    "cba_optimize_intrinsics_semidlt_rccl": (
+        C.c_int32,
+        [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32,
+         c_double_p, c_double_p, c_int32_p, c_double_p, C.c_int32, C.POINTER(CbaOptions), C.POINTER(CbaSummary), c_double_p, c_double_p,
+         c_double_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32],
+    ),
     "cba_estimate_homography_batch": (
         C.c_int32, [C.c_int32, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
     "cba_estimate_planar_pose_batch": (

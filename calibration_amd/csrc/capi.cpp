@@ -1024,6 +1024,78 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
     });
 }
 
+namespace {
+// argument checks shared by the two sharded semi-DLT entry points; false: fewer than 4 views in total (result left default)
+bool semidlt_sharded_args(int32_t n_local, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
+                          int32_t n_total, int32_t first_view, const double* kmtx5, const double* c_T_t, int32_t num_radial,
+                          const double* lo, const double* hi, const int32_t* fixed_idx, int32_t n_fixed, const cba_options* opts,
+                          cba_summary* summary, int32_t n_ranks, int32_t rank, int32_t device) {
+    if (!opts || !summary) throw std::invalid_argument("null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+    if (n_total < 4) {
+        std::memset(summary, 0, sizeof(*summary));
+        summary->termination = CBA_TERM_FAILURE;
+        std::snprintf(summary->report, sizeof(summary->report), "Insufficient views for calibration (at least 4 required).");
+        return false;
+    }
+    if (n_local < 0 || first_view < 0 || first_view + n_local > n_total) throw std::invalid_argument("view range outside the problem");
+    if (!view_offset || !kmtx5 || !c_T_t || (n_local > 0 && (!X || !Y || !u || !v))) throw std::invalid_argument("null argument");
+    if (num_radial < 0 || num_radial > 3) throw std::invalid_argument("num_radial must be in [0, 3]");
+    if ((lo == nullptr) != (hi == nullptr)) throw std::invalid_argument("bounds need both ends");
+    if (n_fixed < 0 || (n_fixed > 0 && !fixed_idx)) throw std::invalid_argument("bad fixed distortion list");
+    for (int i = 0; i < n_local; ++i)
+        if (view_offset[i + 1] < view_offset[i] || view_offset[i + 1] - view_offset[i] > 0x7fffffff) throw std::invalid_argument("bad view offsets");
+    const int ndev = device_count();
+    if (ndev <= 0) throw NoDevice("no HIP device visible: libcalibba has no CPU fallback");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    return true;
+}
+}  // namespace
+
+cba_status cba_optimize_intrinsics_semidlt_sharded(int32_t n_views_local, const int64_t* view_offset, const double* X, const double* Y,
+                                                   const double* u, const double* v, int32_t n_views_total, int32_t first_view,
+                                                   double* kmtx5, double* c_T_t, int32_t num_radial, const double* bounds_lo5,
+                                                   const double* bounds_hi5, const int32_t* fixed_idx, const double* fixed_val,
+                                                   int32_t n_fixed, const cba_options* opts, cba_summary* summary, double* distortion,
+                                                   double* view_errors, double* cov, cba_allreduce_fn fn, void* user, int32_t n_ranks,
+                                                   int32_t rank, int32_t device) {
+    return guarded([&] {
+        if (!semidlt_sharded_args(n_views_local, view_offset, X, Y, u, v, n_views_total, first_view, kmtx5, c_T_t, num_radial, bounds_lo5,
+                                  bounds_hi5, fixed_idx, n_fixed, opts, summary, n_ranks, rank, device))
+            return;
+        if (!fn) throw std::invalid_argument("null allreduce callback");
+        semidlt_solve_sharded(n_views_local, view_offset, X, Y, u, v, n_views_total, first_view, kmtx5, c_T_t, num_radial, bounds_lo5,
+                              bounds_hi5, fixed_idx, fixed_val, n_fixed, opts, summary, distortion, view_errors,
+                              (cov && opts->compute_covariance) ? cov : nullptr, device, fn, user, nullptr);
+    });
+}
+
+cba_status cba_optimize_intrinsics_semidlt_rccl(int32_t n_views_local, const int64_t* view_offset, const double* X, const double* Y,
+                                                const double* u, const double* v, int32_t n_views_total, int32_t first_view,
+                                                double* kmtx5, double* c_T_t, int32_t num_radial, const double* bounds_lo5,
+                                                const double* bounds_hi5, const int32_t* fixed_idx, const double* fixed_val,
+                                                int32_t n_fixed, const cba_options* opts, cba_summary* summary, double* distortion,
+                                                double* view_errors, double* cov, const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES],
+                                                int32_t n_ranks, int32_t rank, int32_t device) {
+    return guarded([&] {
+        if (!id) throw std::invalid_argument("null argument");
+        if (!semidlt_sharded_args(n_views_local, view_offset, X, Y, u, v, n_views_total, first_view, kmtx5, c_T_t, num_radial, bounds_lo5,
+                                  bounds_hi5, fixed_idx, n_fixed, opts, summary, n_ranks, rank, device))
+            return;
+        CBA_HIP(hipSetDevice(device));
+        void* comm = rccl_comm_create(id, n_ranks, rank);
+        try {
+            semidlt_solve_sharded(n_views_local, view_offset, X, Y, u, v, n_views_total, first_view, kmtx5, c_T_t, num_radial, bounds_lo5,
+                                  bounds_hi5, fixed_idx, fixed_val, n_fixed, opts, summary, distortion, view_errors,
+                                  (cov && opts->compute_covariance) ? cov : nullptr, device, nullptr, nullptr, comm);
+        } catch (...) {
+            rccl_comm_destroy(comm, true);  // this rank leaves: its peers' collectives must fail, not hang
+            throw;
+        }
+        rccl_comm_destroy(comm, false);
+    });
+}
+
 cba_status cba_estimate_homography_batch(int32_t n_views, const int64_t* view_offset, const double* X, const double* Y,
                                          const double* u, const double* v, double* h9, int32_t* success) {
     return guarded([&] {

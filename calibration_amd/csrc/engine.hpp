@@ -291,6 +291,11 @@ void semidlt_solve(int n_views, const int64_t* view_offset, const double* X, con
                    double* kappa5, double* poses7, int num_radial, const double* bounds_lo, const double* bounds_hi,
                    const int32_t* fixed_idx, const double* fixed_val, int n_fixed, const cba_options* o, cba_summary* summary,
                    double* distortion, double* view_errors, double* cov, int device);
+void semidlt_solve_sharded(int n_local, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
+                           int n_views_total, int first_view, double* kappa5, double* poses7, int num_radial, const double* bounds_lo,
+                           const double* bounds_hi, const int32_t* fixed_idx, const double* fixed_val, int n_fixed, const cba_options* o,
+                           cba_summary* summary, double* distortion, double* view_errors, double* cov, int device, cba_allreduce_fn fn,
+                           void* user, void* rccl_comm);
 void dlt_homography_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,
                           double* H9, int32_t* ok, int device);
 void planar_seed_batch(int n_views, const int64_t* view_offset, const double* X, const double* Y, const double* u, const double* v,

@@ -713,6 +713,64 @@ def optimize_intrinsics_semidlt(views, initial_guess, init_c_se3_t=None, opts: O
     return IntrinsicsOptimizationResult(result_core(s, c), camera, [pose_to_matrix(p) for p in poses], [float(e) for e in ve[:nv]], dist)
 
 
+def optimize_intrinsics_semidlt_sharded(local_views, first_view: int, n_views_total: int, initial_guess, init_c_se3_t, n_ranks: int,
+                                        rank: int, allreduce=None, rccl_id: Optional[bytes] = None,
+                                        opts: Optional[IntrinsicsOptimOptions] = None, bounds: Optional[CalibrationBounds] = None,
+                                        fixed_distortion_indices=(), fixed_distortion_values=(), device: int = 0
+                                        ) -> IntrinsicsOptimizationResult:
+    """optimize_intrinsics_semidlt with the VIEWS sharded over ranks (cba_optimize_intrinsics_semidlt_sharded / _rccl): this rank
+    passes the observations of views [first_view, first_view + len(local_views)) and the seeds of ALL n_views_total views
+    (init_c_se3_t, the same on every rank).  Transport: ``allreduce(np.ndarray)`` (sums in place across ranks) or ``rccl_id``
+    (the 128 bytes of rccl_unique_id() from one rank).  The result covers the whole problem and is identical on every rank."""
+    opts = opts or IntrinsicsOptimOptions()
+    lib = capi.load_library()
+    nl, nv = len(local_views), int(n_views_total)
+    vs = [np.asarray(v, dtype=np.float64).reshape(-1, 4) for v in local_views]
+    off = np.zeros(nl + 1, dtype=np.int64)
+    np.cumsum([v.shape[0] for v in vs], out=off[1:])
+    allv = np.concatenate(vs, axis=0) if nl else np.zeros((0, 4))
+    X, Y, u, v = (np.ascontiguousarray(allv[:, k]) for k in range(4))
+    K = np.ascontiguousarray(np.asarray(initial_guess, dtype=np.float64).reshape(5)).copy()
+    if len(init_c_se3_t) != nv:
+        raise capi.CbaError(capi.CBA_ERR_INVALID_ARGUMENT, "one seed pose per view of the whole problem")
+    poses = np.ascontiguousarray(np.stack([pose_from_matrix(T) for T in init_c_se3_t])) if nv else np.zeros((1, 7))
+    nr = int(getattr(opts, "num_radial", 2))
+    copts = to_cba_options(opts.core, optimize_skew=opts.optimize_skew)
+    s = CbaSummary()
+    dist, ve = np.zeros(nr + 2), np.zeros(max(nv, 1))
+    dim = 5 + 7 * nv
+    cov = np.zeros((dim, dim)) if opts.core.compute_covariance else None
+    lo = hi = None
+    if bounds is not None:
+        lo = np.array([bounds.fx_min, bounds.fy_min, bounds.cx_min, bounds.cy_min, bounds.skew_min], dtype=np.float64)
+        hi = np.array([bounds.fx_max, bounds.fy_max, bounds.cx_max, bounds.cy_max, bounds.skew_max], dtype=np.float64)
+    fi = np.ascontiguousarray(list(fixed_distortion_indices), dtype=np.int32)
+    fv = np.ascontiguousarray(list(fixed_distortion_values) + [0.0] * (len(fi) - len(list(fixed_distortion_values))), dtype=np.float64)
+    head = (nl, i64ptr(off), dptr(X), dptr(Y), dptr(u), dptr(v), nv, int(first_view), dptr(K), dptr(poses), nr, dptr(lo), dptr(hi),
+            i32ptr(fi) if len(fi) else i32ptr(None), dptr(fv) if len(fi) else dptr(None), len(fi), C.byref(copts), C.byref(s), dptr(dist),
+            dptr(ve), dptr(cov))
+    if rccl_id is not None:
+        idb = (C.c_uint8 * capi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(rccl_id))
+        capi.check(lib, lib.cba_optimize_intrinsics_semidlt_rccl(*head, idb, int(n_ranks), int(rank), int(device)))
+    else:
+        def _cb(buf, count, _user):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        cb = capi.ALLREDUCE_FN(_cb)
+        capi.check(lib, lib.cba_optimize_intrinsics_semidlt_sharded(*head, cb, None, int(n_ranks), int(rank), int(device)))
+    if nv < 4:
+        return IntrinsicsOptimizationResult(OptimResult(), np.zeros(10), [], [])
+    camera = np.concatenate([K, np.zeros(5)])
+    camera[5:5 + nr] = dist[:nr]
+    camera[8:10] = dist[nr:]
+    c = cov if cov is not None and np.any(cov) else None
+    return IntrinsicsOptimizationResult(result_core(s, c), camera, [pose_to_matrix(p) for p in poses], [float(e) for e in ve[:nv]], dist)
+
+
 def estimate_homography_batch(views):
     """Batched estimate_homography (DLT path, homography.cpp:31-43): -> (list of 3x3 H, list of success flags)."""
     lib = capi.load_library()

@@ -378,6 +378,32 @@ cba_status cba_optimize_intrinsics_semidlt(int32_t n_views, const int64_t* view_
                                            const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
                                            cba_summary* summary, double* distortion, double* view_errors, double* cov);
 
+/* The same refinement with the VIEWS sharded over ranks (one process per GPU; BASELINE configs[3] names 8): this rank passes the
+ * observations of views [first_view, first_view + n_views_local) of n_views_total (view_offset [n_views_local + 1] into its own
+ * X, Y, u, v) and the seeds of the whole problem (kmtx5, c_T_t [n_views_total][7], identical on every rank).  The
+ * O(#observations) passes run on the local views; per evaluation the ranks exchange the m(m+1)/2 + m sums that determine the
+ * eliminated distortion coefficients and the table of per-view sums (78 + 22 m doubles per view, every rank filling its own rows),
+ * after which the O(#views) step of the solver runs identically on every rank.  Outputs cover the whole problem and are identical
+ * on every rank: kmtx5, c_T_t, distortion, view_errors [n_views_total], cov [(5 + 7 n_views_total)^2].  Agrees with the
+ * single-GPU call to rounding (the sums are added in another order).  Transport: the host callback of cba_reproj_set_allreduce
+ * (_sharded), or RCCL on device memory with the id from cba_rccl_unique_id on rank 0 (_rccl: a communicator is created for the
+ * call; a rank that fails aborts it so that its peers' collectives fail instead of hanging).
+ * src/estimation/optim/intrinsicssemidlt.cpp:155-191. */
+cba_status cba_optimize_intrinsics_semidlt_sharded(int32_t n_views_local, const int64_t* view_offset, const double* X, const double* Y,
+                                                   const double* u, const double* v, int32_t n_views_total, int32_t first_view,
+                                                   double* kmtx5, double* c_T_t, int32_t num_radial, const double* bounds_lo5,
+                                                   const double* bounds_hi5, const int32_t* fixed_distortion_indices,
+                                                   const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
+                                                   cba_summary* summary, double* distortion, double* view_errors, double* cov,
+                                                   cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank, int32_t device);
+cba_status cba_optimize_intrinsics_semidlt_rccl(int32_t n_views_local, const int64_t* view_offset, const double* X, const double* Y,
+                                                const double* u, const double* v, int32_t n_views_total, int32_t first_view,
+                                                double* kmtx5, double* c_T_t, int32_t num_radial, const double* bounds_lo5,
+                                                const double* bounds_hi5, const int32_t* fixed_distortion_indices,
+                                                const double* fixed_distortion_values, int32_t n_fixed, const cba_options* opts,
+                                                cba_summary* summary, double* distortion, double* view_errors, double* cov,
+                                                const uint8_t id[CBA_RCCL_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank, int32_t device);
+
 /* estimate_homography, DLT path (include/calib/estimation/linear/homography.h, src/estimation/optim/homography.cpp:31-43 ->
  * HomographyEstimator::fit, src/estimation/linear/homographyestimator.cpp:123-146): Hartley-normalised DLT of every view in one
  * launch.  h9 [n_views][9] row-major = T_dst^-1 Hn T_src with Hn(2,2) = 1, returned WITHOUT a final rescale exactly as the reference

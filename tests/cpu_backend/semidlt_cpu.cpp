@@ -10,16 +10,39 @@
 using namespace cba;
 
 namespace {
+// Views [v0, v0 + Vl) of V are local (their observations behind off / X / Y / u / v); the poses cover all V views.  With a reduce
+// callback the evaluator follows the exchange protocol of the product's sharded evaluator (semidlt.hip HipSemiDlt): the pass-1
+// sums cross the ranks before alpha is formed, the per-view tables are gathered as a sum of zero-padded tables.
 struct SerialSemiDlt final : SemiDltEval {
     const int64_t* off;
     const double *X, *Y, *u, *v;
+    int Vl, v0 = 0;
+    cba_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    std::vector<int64_t> counts;
     SerialSemiDlt(int n_views, const int64_t* o, const double* x, const double* y, const double* uu, const double* vv, int num_radial)
-        : off(o), X(x), Y(y), u(uu), v(vv) { V = n_views; nr = num_radial; n_obs = o[n_views]; }
-    SDView view(int i, const double* poses7) const {
+        : off(o), X(x), Y(y), u(uu), v(vv), Vl(n_views) {
+        V = n_views; nr = num_radial; n_obs = o[n_views];
+        for (int i = 0; i < V; ++i) counts.push_back(o[i + 1] - o[i]);
+    }
+    SerialSemiDlt(int n_local, const int64_t* o, const double* x, const double* y, const double* uu, const double* vv, int num_radial,
+                  int n_total, int first_view, cba_allreduce_fn f, void* usr)
+        : off(o), X(x), Y(y), u(uu), v(vv), Vl(n_local), v0(first_view), fn(f), user(usr) {
+        V = n_total; nr = num_radial;
+        std::vector<double> c(V, 0.0);
+        for (int i = 0; i < Vl; ++i) c[v0 + i] = static_cast<double>(o[i + 1] - o[i]);
+        reduce(c.data(), V);
+        n_obs = 0;
+        for (int i = 0; i < V; ++i) { counts.push_back(static_cast<int64_t>(c[i] + 0.5)); n_obs += counts.back(); }
+    }
+    void reduce(double* buf, int64_t n) const {
+        if (fn && fn(buf, n, user) != 0) throw std::runtime_error("allreduce callback failed");
+    }
+    SDView view(int i, const double* poses7) const {  // i: local index
         SDView W;
         W.n = static_cast<int>(off[i + 1] - off[i]);
         W.X = X + off[i]; W.Y = Y + off[i]; W.u = u + off[i]; W.v = v + off[i];
-        block_consts<CH_INTRINSIC>(poses7 + 7 * static_cast<size_t>(i), nullptr, nullptr, W.bc);
+        block_consts<CH_INTRINSIC>(poses7 + 7 * static_cast<size_t>(v0 + i), nullptr, nullptr, W.bc);
         return W;
     }
     template <int NR>
@@ -28,11 +51,12 @@ struct SerialSemiDlt final : SemiDltEval {
         constexpr int m = L::M;
         double acc[L::N1] = {0}, one[L::N1];
         SerialCoop co;
-        for (int i = 0; i < V; ++i) {
+        for (int i = 0; i < Vl; ++i) {
             const SDView W = view(i, p);
             sd_pass1<NR>(W, k, co, one);
             for (int e = 0; e < L::N1; ++e) acc[e] += one[e];
         }
+        reduce(acc, L::N1);
         int e = 0;
         for (int a = 0; a < m; ++a)
             for (int c = 0; c <= a; ++c, ++e) { N[a * m + c] = acc[e]; N[c * m + a] = acc[e]; }
@@ -48,16 +72,20 @@ struct SerialSemiDlt final : SemiDltEval {
         for (int a = 0; a < m; ++a) al[a] = rhs[a];
         vp_chol_solve<m>(Lc, al);
         SerialCoop co;
-        for (int i = 0; i < V; ++i) {
+        if (fn) std::memset(per_view, 0, sizeof(double) * static_cast<size_t>(V) * SDLayout<NR>::N2);
+        for (int i = 0; i < Vl; ++i) {
             const SDView W = view(i, p);
-            sd_pass2_part<NR, 1, 0>(W, k, al, co, per_view + static_cast<size_t>(i) * SDLayout<NR>::N2);
+            sd_pass2_part<NR, 1, 0>(W, k, al, co, per_view + static_cast<size_t>(v0 + i) * SDLayout<NR>::N2);
         }
+        reduce(per_view, static_cast<int64_t>(V) * SDLayout<NR>::N2);
         return true;
     }
     template <int NR>
     void resid_t(const double* k, const double* p, const double* al, double* s) const {
         SerialCoop co;
-        for (int i = 0; i < V; ++i) { const SDView W = view(i, p); s[i] = sd_resid<NR>(W, k, al, co); }
+        for (int i = 0; i < V; ++i) s[i] = 0.0;
+        for (int i = 0; i < Vl; ++i) { const SDView W = view(i, p); s[v0 + i] = sd_resid<NR>(W, k, al, co); }
+        reduce(s, V);
     }
     void normal(const double* k, const double* p, double* N, double* rhs) override {
         switch (nr) { case 0: normal_t<0>(k, p, N, rhs); break; case 1: normal_t<1>(k, p, N, rhs); break;
@@ -129,6 +157,36 @@ int hm_semidlt_solve(int n_views, const int64_t* off, const double* X, const dou
         for (int i = 0; i < n_views; ++i) view_errors[i] = res.view_errors[i];
         if (cov) {
             const size_t dim = 5 + 7 * static_cast<size_t>(n_views);
+            std::memset(cov, 0, sizeof(double) * dim * dim);
+            std::vector<double> c;
+            if (drv.covariance(ssr, c)) std::memcpy(cov, c.data(), sizeof(double) * dim * dim);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_sd_err = e.what();
+        return 1;
+    }
+}
+// the same solve with the views sharded over ranks (what cba_optimize_intrinsics_semidlt_sharded does on the GPU): this rank's views
+// [first_view, first_view + n_local) of n_total; kappa5 / poses7 / view_errors / cov cover the whole problem
+int hm_semidlt_solve_sharded(int n_local, const int64_t* off, const double* X, const double* Y, const double* u, const double* v, int n_total,
+                             int first_view, double* kappa5, double* poses7, int num_radial, const double* lo, const double* hi,
+                             const int32_t* fixed_idx, const double* fixed_val, int n_fixed, const cba_options* o, cba_summary* summary,
+                             double* distortion, double* view_errors, double* cov, cba_allreduce_fn fn, void* user) {
+    try {
+        SerialSemiDlt ev(n_local, off, X, Y, u, v, num_radial, n_total, first_view, fn, user);
+        SemiDltDriver drv(ev, *o);
+        if (lo && hi) { drv.bounds.enabled = true; for (int k = 0; k < 5; ++k) { drv.bounds.lo[k] = lo[k]; drv.bounds.hi[k] = hi[k]; } }
+        drv.solve(kappa5, poses7, summary);
+        SemiDltResult res;
+        double ssr = 0.0;
+        std::vector<int64_t> off_all(static_cast<size_t>(n_total) + 1, 0);
+        for (int i = 0; i < n_total; ++i) off_all[i + 1] = off_all[i] + ev.counts[i];
+        drv.finish(fixed_idx, fixed_val, n_fixed, off_all.data(), res, &ssr);
+        for (int a = 0; a < num_radial + 2; ++a) distortion[a] = res.alpha[a];
+        for (int i = 0; i < n_total; ++i) view_errors[i] = res.view_errors[i];
+        if (cov) {
+            const size_t dim = 5 + 7 * static_cast<size_t>(n_total);
             std::memset(cov, 0, sizeof(double) * dim * dim);
             std::vector<double> c;
             if (drv.covariance(ssr, c)) std::memcpy(cov, c.data(), sizeof(double) * dim * dim);

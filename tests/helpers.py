@@ -86,6 +86,8 @@ def load_hostmath():
     h.hm_semidlt_step.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, PO,
                                   c_double_p, c_double_p]
     h.hm_semidlt_solve.argtypes = SEMIDLT_SOLVE_ARGS
+    # (n_local, off, X, Y, u, v, n_total, first_view, kappa5, poses7 [all], nr, lo, hi, fixed_idx, fixed_val, n_fixed, opts, summary, ...)
+    h.hm_semidlt_solve_sharded.argtypes = SEMIDLT_SOLVE_ARGS[:6] + [C.c_int, C.c_int] + SEMIDLT_SOLVE_ARGS[6:] + [capi.ALLREDUCE_FN, C.c_void_p]
     h.hm_planar_seed.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     h.hm_planar_seed.restype = None
     h.hm_quat_to_angle_axis.argtypes = [c_double_p, c_double_p]
@@ -400,6 +402,26 @@ def semidlt_solve(fn, d, nr, o, lo=None, hi=None, fixed=None, want_cov=True):
             capi.dptr(None if hi is None else np.ascontiguousarray(hi, dtype=float)),
             None if fi is None else fi.ctypes.data_as(c_int32_p), capi.dptr(fv), 0 if not fixed else len(fixed), C.byref(o), C.byref(s),
             capi.dptr(dist), capi.dptr(ve), capi.dptr(cov if want_cov else None))
+    return st, k, p, s, dist, ve, cov
+
+
+def semidlt_solve_sharded(fn, d, nr, o, world, rank, allreduce_cb, lo=None, hi=None, fixed=None):
+    """hm_semidlt_solve_sharded on rank `rank`'s contiguous share of the views of scene d; outputs cover the whole problem."""
+    V = int(d["n_views"])
+    v0, v1 = rank * V // world, (rank + 1) * V // world
+    a, b = int(d["off"][v0]), int(d["off"][v1])
+    off = np.ascontiguousarray(d["off"][v0:v1 + 1] - d["off"][v0])
+    X, Y, u, v = (np.ascontiguousarray(d[k][a:b]) for k in ("X", "Y", "u", "v"))
+    k, p = d["kappa0"].copy(), d["poses0"].copy()
+    s, dist, ve = CbaSummary(), np.zeros(nr + 2), np.zeros(V)
+    cov = np.zeros((5 + 7 * V, 5 + 7 * V))
+    fi = None if not fixed else np.ascontiguousarray([f[0] for f in fixed], dtype=np.int32)
+    fv = None if not fixed else np.ascontiguousarray([f[1] for f in fixed], dtype=np.float64)
+    st = fn(v1 - v0, off.ctypes.data_as(c_int64_p), capi.dptr(X), capi.dptr(Y), capi.dptr(u), capi.dptr(v), V, v0, capi.dptr(k), capi.dptr(p), nr,
+            capi.dptr(None if lo is None else np.ascontiguousarray(lo, dtype=float)),
+            capi.dptr(None if hi is None else np.ascontiguousarray(hi, dtype=float)),
+            None if fi is None else fi.ctypes.data_as(c_int32_p), capi.dptr(fv), 0 if not fixed else len(fixed), C.byref(o), C.byref(s),
+            capi.dptr(dist), capi.dptr(ve), capi.dptr(cov), allreduce_cb, None)
     return st, k, p, s, dist, ve, cov
 
 

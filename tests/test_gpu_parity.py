@@ -686,6 +686,25 @@ def test_semidlt_mirror_api_and_large_problem(gpu_lib):
     assert rb.camera[0] == kgt[0] - 10.0
 
 
+def test_semidlt_rccl_transport_one_rank_equals_the_plain_entry_point(gpu_lib):
+    """cba_optimize_intrinsics_semidlt_rccl: the sharded evaluator (split pass-1 sum / alpha kernels, row-gather of the per-view
+    table, the sums reduced by ncclAllReduce in device memory) on a communicator of ONE rank - all a one-GPU box can run - against
+    the single-GPU entry point, whose pass-1 sum it reproduces in the same order: equal to the last bit.  The multi-rank
+    arithmetic is covered over gloo (tests/test_multirank_gloo.py).  intrinsicssemidlt.cpp:155-191."""
+    from calibration_amd.geometry import pose_from_matrix, pose_to_matrix
+
+    d, _kgt, _agt = helpers.semidlt_scene(8, rows=7, cols=9, noise=0.2, nr=2, seed=5)
+    views = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][:-1], d["off"][1:])]
+    seeds = [pose_to_matrix(p) for p in d["poses0"]]
+    opt = optim.IntrinsicsOptimOptions(core=optim.OptimOptions(epsilon=1e-12, compute_covariance=True), num_radial=2)
+    ref = optim.optimize_intrinsics_semidlt(views, d["kappa0"], seeds, opt)
+    res = optim.optimize_intrinsics_semidlt_sharded(views, 0, 8, d["kappa0"], seeds, 1, 0, rccl_id=optim.rccl_unique_id(), opts=opt, device=0)
+    assert res.core.success == ref.core.success and res.core.iterations == ref.core.iterations and res.core.final_cost == ref.core.final_cost
+    assert np.array_equal(res.camera, ref.camera) and np.array_equal(res.distortion, ref.distortion)
+    assert np.array_equal(np.stack([pose_from_matrix(T) for T in res.c_se3_t]), np.stack([pose_from_matrix(T) for T in ref.c_se3_t]))
+    assert np.array_equal(res.core.covariance, ref.core.covariance) and res.view_errors == ref.view_errors
+
+
 # ---- batched estimate_planar_pose on the GPU (SURVEY.md §8f rank 1) -------------------------------------------------------------
 def test_planar_seed_batch_on_gpu(gpu_lib):
     from tests.planar_seed import estimate_planar_pose

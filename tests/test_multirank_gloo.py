@@ -125,6 +125,72 @@ def test_two_ranks_match_one_rank(hostmath, tmp_path, kind, okw, world):
         assert int(res[0]["first"]) == 0 and int(res[1]["first"]) == res[0]["view"].reshape(-1, 7).shape[0]
 
 
+# ---- semi-DLT with the views sharded: the exchange protocol of semidlt.hip's evaluator on the host build, 2 processes over gloo ---
+def _semidlt_cpu_worker(rank, world, port, n_views, case, outdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calibration_amd import capi
+    from tests import helpers
+
+    hm = helpers.load_hostmath()
+    d, _kgt, _agt = helpers.semidlt_scene(n_views, noise=0.2, nr=2, seed=5)
+    calls = []
+
+    def allreduce(buf, count, _user):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(count),)))
+        dist.all_reduce(t)
+        calls.append(int(count))
+        return 0
+
+    lo, hi, fixed = _semidlt_case(d, case)
+    o = helpers.options(epsilon=1e-12)
+    st, k, p, s, dist_, ve, cov = helpers.semidlt_solve_sharded(hm.hm_semidlt_solve_sharded, d, 2, o, world, rank, capi.ALLREDUCE_FN(allreduce), lo, hi, fixed)
+    assert st == 0, hm.hm_semidlt_last_error()
+    np.savez(os.path.join(outdir, f"sdc{rank}.npz"), k=k, p=p, dist=dist_, ve=ve, cov=cov, cost=s.final_cost, iters=s.iterations, term=s.termination,
+             sizes=np.array(calls))
+    dist.destroy_process_group()
+
+
+def _semidlt_case(d, case):
+    if case == "bounds":
+        return [0.0, 0.0, 0.0, 0.0, -1.0], [float(d["kappa0"][0]) + 3.0, 4000.0, 4000.0, 4000.0, 1.0], None
+    if case == "fixed":
+        return None, None, [(1, 0.01)]
+    return None, None, None
+
+
+@pytest.mark.parametrize("n_views,world,case", [(6, 2, "plain"), (7, 2, "bounds"), (5, 3, "fixed")])
+def test_semidlt_views_sharded_over_ranks_match_one_rank(hostmath, tmp_path, n_views, world, case):
+    """optimize_intrinsics_semidlt (intrinsicssemidlt.cpp:155-191) with the views sharded: per evaluation the ranks exchange the 14
+    pass-1 sums behind the eliminated distortion coefficients and gather the per-view table as a sum of zero-padded tables; the
+    O(#views) arrow / Woodbury step then runs identically everywhere.  Same termination and iteration count as one rank, results
+    equal to rounding, identical across ranks; exchange sizes are the protocol's."""
+    import torch.multiprocessing as mp
+
+    from tests import helpers
+
+    mp.spawn(_semidlt_cpu_worker, args=(world, _free_port(), n_views, case, str(tmp_path)), nprocs=world, join=True)
+    d, _kgt, _agt = helpers.semidlt_scene(n_views, noise=0.2, nr=2, seed=5)
+    lo, hi, fixed = _semidlt_case(d, case)
+    o = helpers.options(epsilon=1e-12)
+    st, k, p, s, dist_, ve, cov = helpers.semidlt_solve(hostmath.hm_semidlt_solve, d, 2, o, lo, hi, fixed)
+    assert st == 0
+    res = [np.load(os.path.join(tmp_path, f"sdc{r}.npz")) for r in range(world)]
+    for r in res:
+        assert int(r["term"]) == s.termination and int(r["iters"]) == s.iterations
+        assert set(r["sizes"].tolist()) <= {n_views, 14, n_views * (78 + 22 * 4)} and len(r["sizes"]) >= 3
+        assert np.abs(r["k"] - k).max() <= 1e-9 * np.abs(k).max() and np.abs(r["p"] - p).max() <= 1e-10
+        assert np.abs(r["dist"] - dist_).max() <= 1e-10 and np.abs(r["ve"] - ve).max() <= 1e-10
+        assert abs(float(r["cost"]) - s.final_cost) <= 1e-10 * max(1.0, s.final_cost)
+        assert np.abs(r["cov"] - cov).max() <= 1e-7 * np.abs(cov).max()
+    for r in res[1:]:
+        assert np.array_equal(res[0]["k"], r["k"]) and np.array_equal(res[0]["p"], r["p"]) and np.array_equal(res[0]["cov"], r["cov"])
+
+
 # ---- GPU tier: the same 2-rank protocol with the REAL engine (HIP kernels per rank, both ranks on GPU 0), gloo transport --------
 def _gpu_worker(rank, world, port, kind, okw, outdir):
     import torch
@@ -251,6 +317,91 @@ def test_axxb_sharded_over_ranks_matches_one_gpu(tmp_path, n_poses, world):
         assert np.abs(r["cov"] - ref.core.covariance).max() <= 1e-8 * np.abs(ref.core.covariance).max()
     for r in res[1:]:  # every rank ran the same LM on the same sums
         assert np.array_equal(res[0]["pose"], r["pose"])
+
+
+def _semidlt_shard(d, world, rank):
+    """Contiguous view ranges balanced by count: (first_view, local views [n][4])."""
+    nv = int(d["n_views"])
+    v0, v1 = rank * nv // world, (rank + 1) * nv // world
+    views = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][v0:v1], d["off"][v0 + 1:v1 + 1])]
+    return v0, views
+
+
+def _semidlt_worker(rank, world, port, n_views, case, outdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from calibration_amd import optim
+    from calibration_amd.geometry import pose_from_matrix, pose_to_matrix
+    from tests import helpers
+
+    d, _kgt, _agt = helpers.semidlt_scene(n_views, rows=7, cols=9, noise=0.2, nr=2, seed=5)
+    v0, views = _semidlt_shard(d, world, rank)
+    calls = []
+
+    def allreduce(arr):
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t)
+        calls.append(arr.size)
+
+    opt = optim.IntrinsicsOptimOptions(core=optim.OptimOptions(epsilon=1e-12, compute_covariance=True), num_radial=2)
+    kw = dict(bounds=optim.CalibrationBounds(fx_max=float(d["kappa0"][0]) + 3.0, fy_max=4000.0, cx_max=4000.0, cy_max=4000.0)) if case == "bounds" else \
+        dict(fixed_distortion_indices=[1], fixed_distortion_values=[0.01]) if case == "fixed" else {}
+    r = optim.optimize_intrinsics_semidlt_sharded(views, v0, n_views, d["kappa0"], [pose_to_matrix(p) for p in d["poses0"]], world, rank,
+                                                  allreduce=allreduce, opts=opt, device=0, **kw)
+    np.savez(os.path.join(outdir, f"sd{rank}.npz"), camera=r.camera, dist=r.distortion, poses=np.stack([pose_from_matrix(T) for T in r.c_se3_t]),
+             ve=np.array(r.view_errors), cov=r.core.covariance if r.core.covariance is not None else np.zeros(1), cost=r.core.final_cost,
+             success=r.core.success, iters=r.core.iterations, sizes=np.array(calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_views,world,case", [(9, 2, "plain"), (10, 3, "bounds"), (5, 4, "fixed"), (4, 5, "plain")])
+def test_semidlt_sharded_over_ranks_matches_one_gpu(tmp_path, n_views, world, case):
+    """optimize_intrinsics_semidlt with the VIEWS sharded over 2 / 3 / 4 / 5 ranks (each its own process on GPU 0, sums over gloo;
+    with 4 views and 5 ranks one rank holds no view at all) against the single-GPU entry point: per evaluation one exchange of the
+    m(m+1)/2 + m = 14 sums that determine the eliminated distortion coefficients and one of the per-view table (166 doubles per
+    view); every rank then runs the same O(#views) step.  src/estimation/optim/intrinsicssemidlt.cpp:155-191."""
+    import torch.multiprocessing as mp
+
+    from calibration_amd import optim
+    from calibration_amd.geometry import pose_from_matrix, pose_to_matrix
+    from tests import helpers
+
+    ctx = mp.start_processes(_semidlt_worker, args=(world, _free_port(), n_views, case, str(tmp_path)), nprocs=world, join=False, start_method="spawn")
+    import time
+
+    deadline = time.time() + 180
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("sharded semi-DLT did not finish in 180 s")
+    d, _kgt, _agt = helpers.semidlt_scene(n_views, rows=7, cols=9, noise=0.2, nr=2, seed=5)
+    views = [np.c_[d["X"][a:b], d["Y"][a:b], d["u"][a:b], d["v"][a:b]] for a, b in zip(d["off"][:-1], d["off"][1:])]
+    opt = optim.IntrinsicsOptimOptions(core=optim.OptimOptions(epsilon=1e-12, compute_covariance=True), num_radial=2)
+    kw = dict(bounds=optim.CalibrationBounds(fx_max=float(d["kappa0"][0]) + 3.0, fy_max=4000.0, cx_max=4000.0, cy_max=4000.0)) if case == "bounds" else \
+        dict(fixed_distortion_indices=[1], fixed_distortion_values=[0.01]) if case == "fixed" else {}
+    ref = optim.optimize_intrinsics_semidlt(views, d["kappa0"], [pose_to_matrix(p) for p in d["poses0"]], opt, **kw)
+    ref_poses = np.stack([pose_from_matrix(T) for T in ref.c_se3_t])
+    res = [np.load(os.path.join(tmp_path, f"sd{r}.npz")) for r in range(world)]
+    n2 = 78 + 22 * 4
+    for r in res:
+        assert bool(r["success"]) == ref.core.success and int(r["iters"]) == ref.core.iterations
+        assert set(r["sizes"].tolist()) <= {n_views, 14, n_views * n2}  # view sizes once, then [N | A^T b] and the per-view table (or |r|^2 per view)
+        assert np.abs(r["camera"] - ref.camera).max() <= 1e-9 * np.abs(ref.camera).max()
+        assert np.abs(r["dist"] - ref.distortion).max() <= 1e-10
+        assert np.abs(r["poses"] - ref_poses).max() <= 1e-10
+        assert abs(float(r["cost"]) - ref.core.final_cost) <= 1e-10 * max(1.0, ref.core.final_cost)
+        assert np.abs(r["ve"] - np.array(ref.view_errors)).max() <= 1e-10
+        assert np.abs(r["cov"] - ref.core.covariance).max() <= 1e-7 * np.abs(ref.core.covariance).max()
+        if case == "bounds":
+            assert r["camera"][0] == float(d["kappa0"][0]) + 3.0
+    for r in res[1:]:  # every rank ran the same solve on the same sums
+        assert np.array_equal(res[0]["camera"], r["camera"]) and np.array_equal(res[0]["poses"], r["poses"])
 
 
 # ---- CPU tier: many random problems over 2-4 IN-PROCESS ranks (threads; the all-reduce is a barrier + sum in Python) ------------------
