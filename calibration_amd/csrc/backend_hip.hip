@@ -1081,7 +1081,7 @@ struct HipBackend final : Backend {
         ensure_pack(L);
         st.pin_lmp.p[0] = radius;
         st.pin_lmp.p[1] = 0.0;
-        enqueue_system(0.0, false, s.n_blocks != 0, constrained, 0, L, 0);  // (the cost slot is rewritten with the current value; only [nfail .. g] travels)
+        enqueue_system(0.0, false, s.n_blocks != 0, constrained, 0, L, 0, 0);  // only [nfail .. g] travels (the cost slot, outside that range, is not a cost after this)
         exchange(L.nfail, L.gmax - L.nfail, ar, pack);
     }
     bool sys_step(const double* delta_sh, double huber, double radius_next, bool constrained, const PackLayout& L, const AllReduce& ar,

@@ -136,15 +136,17 @@ inline double argmin_on(const std::vector<LineSample>& samples, double lo, doubl
 
 // The search.  sample(step, with_slope) evaluates the objective (and, when asked, its directional derivative) at
 // Plus(x, step * direction).  Returns the step size to scale the direction with; <= 0 means the search failed and the step is
-// left as it is.  evaluations: number of sample() calls made.
+// left as it is.  evaluations: number of sample() calls made.  The step size returned is that of the LAST sample() call.
 template <class Sample>
-double armijo_line_search(double value0, double slope0, double direction_max_abs, Sample&& sample, int* evaluations) {
+double armijo_line_search(double value0, double slope0, double direction_max_abs, Sample&& sample, int* evaluations,
+                          const LineSample* first = nullptr) {
     constexpr double kDecrease = 1e-4, kMaxContraction = 1e-3, kMinContraction = 0.6, kMinStep = 1e-9;
     constexpr int kMaxIterations = 20;
     LineSample start;
     start.step = 0.0; start.value = value0; start.slope = slope0; start.has_value = start.has_slope = true;
-    LineSample prev, cur = sample(1.0, false);
-    *evaluations = 1;
+    // first: the sample at step size 1 when the caller has it already (the LM's trial point IS that sample: no second evaluation)
+    LineSample prev, cur = first ? *first : sample(1.0, false);
+    *evaluations = first ? 0 : 1;
     for (int it = 0; !cur.has_value || cur.value > value0 + kDecrease * slope0 * cur.step;) {
         if (++it >= kMaxIterations) return -1.0;
         if (cur.has_value && !cur.has_slope) { cur = sample(cur.step, true); ++*evaluations; }  // the cubic wants the slope here

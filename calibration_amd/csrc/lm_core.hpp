@@ -422,7 +422,9 @@ class LMDriver {
             return ls;
         };
         int evals = 0;
-        double a = armijo_line_search(cost0, slope0, dmax, sample, &evals);
+        LineSample first;  // the trial point the controller has just judged
+        first.step = 1.0; first.value = rec[CS_CAND_COST]; first.has_value = std::isfinite(first.value);
+        double a = armijo_line_search(cost0, slope0, dmax, sample, &evals, &first);
         xs_.line_search_evaluations += evals;
         if (!(a > 0.0)) {  // search failed: the full step, re-established on the device (one more sample)
             a = 1.0;
@@ -554,7 +556,9 @@ class LMDriver {
                             return ls;
                         };
                         int evals = 0;
-                        double a = armijo_line_search(cost_, slope0, dmax, sample, &evals);
+                        LineSample first;  // the trial point just evaluated
+                        first.step = 1.0; first.value = st.cost; first.has_value = std::isfinite(first.value);
+                        double a = armijo_line_search(cost_, slope0, dmax, sample, &evals, &first);
                         xs_.line_search_evaluations += evals;
                         if (!(a > 0.0)) {  // search failed: the full step, re-established on the device (one more sample)
                             a = 1.0;

@@ -749,6 +749,7 @@ CBA_HD void ctl_run(TM& tm, const CtlView& V, int mode, int flag) {
                 if (tm.tid() == 0) {
                     V.scal[CS_MODEL_CHANGE] = model_change;
                     V.scal[CS_SLOPE0] = gd;
+                    V.scal[CS_CAND_COST] = cand;  // (the host's search starts from this sample)
                     V.scal[CS_EXPECT] = CTL_LINE_SEARCH;
                 }
             } else if (ctl_decide(tm, V, speculated, model_change, cand, step2, xnorm2)) {

@@ -601,7 +601,8 @@ def gap_category(rep: dict, cost_a: float, cost_b: float, iters=(0, 0), share=0.
                              (condition number > 1e6): two correct solvers that differ by rounding end apart IN THAT VALLEY;
       "stopping-resolution"  the two end points are closer than the solvers' own stopping rule can tell apart: Ceres stops when
                              |dcost| <= eps cost, and the quadratic model prices the whole displacement between them at no more
-                             than 4 eps cost (typically one solver took one step more than the other);
+                             than 4 eps cost - 10 eps cost when one solver did take a step more than the other: at a linear
+                             rate r the cost still to go at the stop is r / (1 - r) times the last decrease, 10 covers r <= 0.91;
       "slow-convergence"     a well-conditioned problem on which the trust-region iteration itself converges linearly with a rate
                              near 1 (per-block Huber weights with every block in the linear regime: the Gauss-Newton model
                              over-states the curvature) - both solvers need >= 50 iterations and stop by the function tolerance
@@ -613,7 +614,7 @@ def gap_category(rep: dict, cost_a: float, cost_b: float, iters=(0, 0), share=0.
     consistent = rep["outside"] <= 1e-9 and (cmax <= 1e-6 or abs(cost_a - cost_b) <= 2.0 * rep["predicted_cost_gap"] + 1e-10 * cmax)
     if consistent and rep["kappa"] > 1e6 and rep["weak_share"] >= share:
         return "weak-direction"
-    if consistent and rep["predicted_cost_gap"] <= 4.0 * eps * cmax:
+    if consistent and rep["predicted_cost_gap"] <= (10.0 if iters[0] != iters[1] else 4.0) * eps * cmax:
         return "stopping-resolution"
     if consistent and min(iters) >= 50 and abs(cost_a - cost_b) <= 1e-8 * cmax:
         return "slow-convergence"

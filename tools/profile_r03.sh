@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement pass on the GPU box (via gpurun, from the repo root).  Outputs under gpurun_out/r03_*; the summaries cited in
-# DESIGN.md are copied into profiles/ afterwards.  usage: bash tools/profile_r03.sh [part ...]   parts: evalpmc bench lm trace
+# DESIGN.md are copied into profiles/ afterwards.  usage: bash tools/profile_r03.sh [part ...]   parts: evalpmc bench lm trace modebpmc
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out"
@@ -34,6 +34,14 @@ lm)
     CBA_LM_CTL=$ctl CBA_LM_TIMING=1 python3 tools/exp.py lm c1h c2 c3 c3e c5 >> "$OUT/r03_lm_ctl$ctl.jsonl" 2>> "$OUT/r03_lm_ctl$ctl.err" || echo "exp lm failed"
   done
   grep -h shape "$OUT/r03_lm_ctl1.jsonl" | cut -c1-140
+  ;;
+modebpmc)
+  # issue / stall split of the Mode B kernels (C2 direct form in bench.py's mode_b section, C3 moment form in lm_strong): two counter
+  # passes, nothing but --pmc (tools/pmc_valu_summary.py r03 -> profiles/r03_pmc_valu_mode_a_b.json)
+  rm -rf "$OUT/r03_prof_valu" "$OUT/r03_prof_valu2"
+  (cd /tmp && rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/r03_prof_valu" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu > "$OUT/r03_bench_valu.json" 2> "$OUT/r03_bench_valu.err") || echo "valu run failed"
+  (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/r03_prof_valu2" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu > "$OUT/r03_bench_valu2.json" 2> "$OUT/r03_bench_valu2.err") || echo "valu2 run failed"
+  python3 tools/pmc_valu_summary.py r03 && rm -rf "$OUT/r03_prof_valu" "$OUT/r03_prof_valu2" || echo "summary failed (raw counter files kept)"
   ;;
 trace)
   rm -rf "$OUT/r03_prof_c3e"
