@@ -294,14 +294,18 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     {
         std::vector<Tile> ta, tb;
         e.blk_tile_off.assign(d.n_blocks + 1, 0);
+        // Mode B / R tile length: a tile pays one wave reduction and one partial row whatever its length (8 - 11 % of a 2048-observation
+        // tile's instructions; three rows per block to sum again at 5000 observations per block), so tiles grow with the problem as long
+        // as ~4096 workgroups remain to fill the chip: C3 (32 000 blocks of 5000) and its 8-GPU share get one tile per block.
+        const int64_t tile_b = std::max<int64_t>(TILE_B, (e.blk_offset[d.n_blocks] / 4096 + 255) / 256 * 256);
         for (int b = 0; b < d.n_blocks; ++b) {
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
             const int64_t np = (n + 1) & ~int64_t(1);
             for (int64_t s = 0; s < np; s += TILE_A)
                 ta.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_A, np - s)), e.pad_offset[b] + s, e.xy_offset[b] + s, 0});
             e.blk_tile_off[b] = static_cast<int64_t>(tb.size());
-            for (int64_t s = 0; s < n; s += TILE_B)
-                tb.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(TILE_B, n - s)), e.pad_offset[b] + s, e.xy_offset[b] + s, 0});
+            for (int64_t s = 0; s < n; s += tile_b)
+                tb.push_back(Tile{b, static_cast<int32_t>(std::min<int64_t>(tile_b, n - s)), e.pad_offset[b] + s, e.xy_offset[b] + s, 0});
         }
         e.blk_tile_off[d.n_blocks] = static_cast<int64_t>(tb.size());
         e.n_tilesA = static_cast<int64_t>(ta.size());

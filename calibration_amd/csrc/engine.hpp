@@ -15,7 +15,7 @@
 //   bc                [n_blocks][36] per-block chain constants (reproj_math.hpp BC_*)
 //   sd                [n_cams][36]  Scheimpflug per-camera constants (SD_*)
 //   intr/cam/view/target            parameter blocks, current [0] and trial [1] copies
-//   tilesA / tilesB                 wave-tile tables: a tile is <=128 (Mode A) / <=TILE_B (Mode B, R)
+//   tilesA / tilesB                 wave-tile tables: a tile is <=128 (Mode A) / >= TILE_B except a block's last (Mode B, R)
 //                                    consecutive observations of ONE block, processed by ONE wavefront
 //   partial           [n_tilesB][NACC]  per-tile Mode B sums;  blk_acc [n_blocks][NACC] per-block sums
 #pragma once
@@ -159,8 +159,8 @@ struct Tile {          // 32 bytes, read with scalar loads (wave-uniform)
 };
 
 constexpr int TILE_A = 128;  // Mode A: 64 lanes x 2 adjacent observations
-constexpr int OPL_B = 32;    // Mode B/R: observations per lane per tile (2048-observation tiles: the wave reduction and the
-                             // tile partial rows are paid once per tile)
+constexpr int OPL_B = 32;    // Mode B/R: observations per lane of the SHORTEST full tile (2048 observations: the wave reduction and the
+                             // tile's partial row are paid once per tile; large problems use longer tiles, capi.cpp)
 constexpr int TILE_B = 64 * OPL_B;
 
 struct Engine {

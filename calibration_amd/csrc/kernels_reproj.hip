@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_mom(const Tile* __restrict__ 
     if (lane < t.count) { xc = X[t.xy_start + lane]; yc = Y[t.xy_start + lane]; uc = u[t.start + lane]; vc = v[t.start + lane]; }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see k_normal_eq
 #pragma unroll 1
-    for (int k = 0; k < OPL_B; ++k) {
+    for (int k = 0;; ++k) {  // (until the tile is done: the break below)
         const int j = lane + 64 * k;
         if (64 * k >= t.count) break;  // wave-uniform
         T xn = T(0), yn = T(0), un = T(0), vn = T(0);

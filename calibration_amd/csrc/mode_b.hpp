@@ -81,7 +81,7 @@ __device__ __forceinline__ void normal_eq_tile_split(const Tile t, int lane, con
     // pass wait for its own prefetch (s_waitcnt vmcnt(3) before the first use), which defeats the pipeline
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll 1
-    for (int k = 0; k < OPL_B; ++k) {
+    for (int k = 0;; ++k) {  // (until the tile is done: the break below)
         const int j = lane + 64 * k;
         if (64 * k >= t.count) break;  // wave-uniform
         T xn = T(0), yn = T(0), un = T(0), vn = T(0);
@@ -220,7 +220,7 @@ __device__ __forceinline__ double resid_tile(const Tile t, int lane, const T* bc
                                              const T* u, const T* v) {
     double s = 0.0;
 #pragma unroll 4
-    for (int k = 0; k < OPL_B; ++k) {
+    for (int k = 0;; ++k) {  // (until the tile is done: the break below)
         const int j = lane + 64 * k;
         if (64 * k >= t.count) break;  // wave-uniform
         if (j < t.count) {
