@@ -106,7 +106,9 @@ __global__ __launch_bounds__(CTL_THREADS) void k_lm_ctl(CtlView V, int mode, int
     __shared__ int s_ok;
     __shared__ unsigned long long s_last;
     const int tid = threadIdx.x, n = V.n;
-    const bool small = n <= CTL_SMALL_N;
+    const bool small = LDS_A || n <= CTL_SMALL_N;  // (LDS_A: n <= CTL_LDS_MAX_N <= CTL_SMALL_N, known at compile time: every pointer below
+                                                   // is then an LDS pointer on every path and the compiler addresses it as one)
+    static_assert(CTL_LDS_MAX_N <= CTL_SMALL_N, "the LDS form keeps the short arrays in LDS too");
     double *g_gc = V.gc, *g_scale2 = V.scale2, *g_hdiag = V.hdiag;
     int* g_idx = V.idx;
     int8_t* g_eff = V.eff;

@@ -128,17 +128,33 @@ CBA_HD void ctl_decode(const CtlView& V, int i, int* cam, int* lc) {
     *cam = i / V.PC;
     *lc = 6 + i - *cam * V.PC;
 }
-CBA_HD int ctl_intr_base(const CtlView& V, int c) { return V.chain == CH_INTRINSIC ? 0 : V.sh_base + c * V.PC + 6; }
-CBA_HD int ctl_campose_base(const CtlView& V, int c) { return V.sh_base + c * V.PC; }
+template <class VW>
+CBA_HD int ctl_intr_base(const VW& V, int c) { return V.chain == CH_INTRINSIC ? 0 : V.sh_base + c * V.PC + 6; }
+template <class VW>
+CBA_HD int ctl_campose_base(const VW& V, int c) { return V.sh_base + c * V.PC; }
 // packed upper triangle of the n x n Schur term as it travels in the pack
 CBA_HD int64_t ctl_sidx(int n, int i, int j) { return i <= j ? static_cast<int64_t>(i) * n - static_cast<int64_t>(i) * (i - 1) / 2 + (j - i)
                                                               : static_cast<int64_t>(j) * n - static_cast<int64_t>(j) * (j - 1) / 2 + (i - j); }
 
 // Plus on the shared blocks with the fx, fy >= 0 projection (LMDriver::shared_plus): xo = Plus(x, delta); the team's totals of
 // |xo - x|^2 and |x|^2 over the variable blocks.  xo is complete for every thread on return.
-// (used for the gradient norm and for the trial point: NOT inlined, so that the quaternion update's sin / cos exist once in the code)
+// (used for the gradient norm and for the trial point: NOT inlined, so that the quaternion update's sin / cos exist once in the
+// code.  Everything it needs travels BY VALUE: a reference to the view or to the team would force the caller to keep them in
+// memory - on the GPU that is scratch, and every pointer read back from scratch has lost its address space: the whole controller
+// then runs on flat loads and stores instead of LDS / global ones.)
+struct CtlPlusView {
+    int n_cams, PI, PC, sh_base, chain, intr_var, target_var;
+    int64_t pk_cam, pk_target;
+    const int8_t* cam_var;
+};
+struct CtlNorms {
+    double step2, xnorm2;
+};
+CBA_HD CtlPlusView ctl_plus_view(const CtlView& V) {
+    return CtlPlusView{V.n_cams, V.PI, V.PC, V.sh_base, V.chain, V.intr_var, V.target_var, V.pk_cam, V.pk_target, V.cam_var};
+}
 template <class TM>
-CBA_NOINLINE void ctl_plus(TM& tm, const CtlView& V, const double* x, const double* delta, double* xo, double* step2, double* xnorm2) {
+CBA_NOINLINE CtlNorms ctl_plus(TM tm, CtlPlusView V, const double* x, const double* delta, double* xo) {
     double s2 = 0.0, x2 = 0.0;
     const int PI = V.PI;
     for (int i = tm.tid(); i < V.n_cams * PI; i += tm.size()) {
@@ -175,8 +191,10 @@ CBA_NOINLINE void ctl_plus(TM& tm, const CtlView& V, const double* x, const doub
             for (int k = 0; k < 7; ++k) { s2 += (o[k] - q[k]) * (o[k] - q[k]); x2 += q[k] * q[k]; }
         }
     }
-    *step2 = tm.sum(s2);
-    *xnorm2 = tm.sum(x2);
+    CtlNorms r;
+    r.step2 = tm.sum(s2);
+    r.xnorm2 = tm.sum(x2);
+    return r;
 }
 
 // the shared blocks' share of Ceres' gradient max-norm (LMDriver::shared_gmax); clobbers xs and x_tmp
@@ -190,8 +208,7 @@ CBA_HD double ctl_shared_gmax(TM& tm, const CtlView& V) {
     }
     for (int i = tm.tid(); i < V.n; i += tm.size()) V.xs[i] = V.eff[i] ? -V.gc[i] : 0.0;
     tm.sync();
-    double s2, x2;
-    ctl_plus(tm, V, V.x_cur, V.xs, V.x_tmp, &s2, &x2);
+    (void)ctl_plus(tm, ctl_plus_view(V), V.x_cur, V.xs, V.x_tmp);
     for (int i = tm.tid(); i < V.n_cams * V.PI; i += tm.size()) m = fmax(m, fabs(V.x_tmp[i] - V.x_cur[i]));
     if (V.chain != CH_INTRINSIC)
         for (int i = tm.tid(); i < 7 * V.n_cams; i += tm.size()) m = fmax(m, fabs(V.x_tmp[V.pk_cam + i] - V.x_cur[V.pk_cam + i]));
@@ -599,7 +616,8 @@ CBA_HD void ctl_iterate(TM& tm, const CtlView& V) {
     const int n = V.n;
     const double* delta = V.x_trial + V.pk_delta;
     double s2, x2;
-    ctl_plus(tm, V, V.x_cur, delta, V.x_trial, &s2, &x2);
+    const CtlNorms nrm = ctl_plus(tm, ctl_plus_view(V), V.x_cur, delta, V.x_trial);
+    s2 = nrm.step2; x2 = nrm.xnorm2;
     tm.tick(V, CP_PLUS);
     // the shared-shared part of Ceres' model cost change -g^T d - 1/2 d^T H d; the views contribute theirs with the step's exchange
     // (H_cc is symmetric: thread (group r, column j) adds the rows r, r + G, ... of column j, so neighbours read neighbours)
