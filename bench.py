@@ -251,8 +251,9 @@ def main():
         lm = lm_box.get("lm") or ({"error": f"LM solve did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else None)
         lm_strong = lm_box.get("lm_strong") or ({"error": f"did not finish within {args.lm_timeout:.0f} s (watchdog)"} if lm_hung else None)
 
-    # ---- BASELINE.json configs[0] (20 views x 88 points, the reference's own test size), rank 0 only: the whole LM as one
-    # resident single-workgroup kernel launch (resident_lm.hip) and the complete call the reference's pipeline makes
+    # ---- BASELINE.json configs[0] (20 views x 88 points, the reference's own test size), rank 0 only: the complete call the
+    # reference's pipeline makes (handle + LM + covariance + release), in the form the automatic mode picks for this size
+    # (the report says which: the staged iteration since round 3, the resident single-launch kernel below ~10 views x 88 points)
     lm_c1 = None
     if rank == 0 and not args.no_lm and not lm_hung:
         try:

@@ -714,12 +714,13 @@ bool resident_lm_eligible(const Engine& e, const cba_options& o) {
     if (s.n_blocks == 0 || s.nsh > RES_NSH_MAX || s.n_cams > RES_MAX_CAMS) return false;
     if (st->resident_mode == 1) {
         if (st->resident_max_obs >= 0) return s.n_obs <= st->resident_max_obs;  // CBA_LM_RESIDENT_MAX_OBS
-        // Measured crossover with the host-driven iteration (tools/exp_resident.py, one MI355X, end of round 2): per LM step the
-        // resident kernel costs ~38 + 1.2 n_views + 0.0105 n_obs us on the intrinsic chain against ~86 us host-driven (flat up to
-        // 4e4 observations; 108 + 0.003 n_obs before the step's kernels and its wait were trimmed).  The two-pose chains need six
-        // register passes over 276-325 sums on ONE CU: 109 us per step at 200 observations against 91 (EXTRINSIC), 88 against 72
-        // at 360 (BUNDLE) - the host-driven iteration wins at every size measured, so the automatic mode leaves them to it.
-        if (s.chain == CBA_CHAIN_INTRINSIC) return 1.2 * s.n_views + 0.0105 * static_cast<double>(s.n_obs) <= 48.0;
+        // Measured crossover with the staged iteration (tools/exp.py resident, one MI355X, end of round 3): per LM step the resident
+        // kernel costs ~45 + 1.0 n_views + 0.0105 n_obs us on the intrinsic chain against 71 - 80 us staged (flat up to 4e4
+        // observations; 86 before the small stages shared launches and the controller kernel kept its pointers' address spaces):
+        // 10 x 88 points 61 vs 87, 10 x 144 68 vs 72, 20 x 88 (BASELINE configs[0]) 80 vs 72, 6 x 400 78 vs 80, 30 x 88 110 vs 71.
+        // The two-pose chains need six register passes over 276-325 sums on ONE CU: the staged iteration wins at every size
+        // measured (extrinsic 200 observations 111 vs 81 us, bundle 360 88 vs 80), so the automatic mode leaves them to it.
+        if (s.chain == CBA_CHAIN_INTRINSIC) return 1.0 * s.n_views + 0.0105 * static_cast<double>(s.n_obs) <= 28.0;
         return false;
     }
     return true;

@@ -229,7 +229,7 @@ cba_status cba_reproj_solve(cba_reproj* h, const cba_options* opts, cba_summary*
  * 2: "resident" - the whole solve in ONE launch of a single-workgroup kernel, for problems too small to fill the chip (the
  * sizes the reference's own tests and pipelines run); falls back to 0 when the kernel cannot take the problem (reduced system
  * wider than 80, > 16 cameras, a transport set).  1 (default): resident below the measured crossover with the staged form
- * (intrinsic chain: 1.2 n_views + 0.0105 n_obs <= 48, e.g. 20 views x 88 points), staged otherwise.
+ * (intrinsic chain: n_views + 0.0105 n_obs <= 28, e.g. 10 views x 88 points; 20 x 88 is already faster staged), staged otherwise.
  * 3 (diagnostic, for A/B measurements): as 0, but the reduced solve and the step decision run on the host from a copy of the
  * reduced pack, as they did before the controller existed.
  * All forms follow the same rules, take the same decisions and agree to rounding. */
