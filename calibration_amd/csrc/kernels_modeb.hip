@@ -40,6 +40,7 @@ struct DirectForm {
     using D = DirectRows<CHAIN, MODEL>;
     static constexpr int NROW = D::N, NPARTS = SPLIT::parts, NTOT = D::PL * (D::PL + 1) / 2 + D::PL + 1;
     static constexpr int MINW = CBA_NE_DIRECT_MINW;
+    static constexpr bool DIRECT = true;  // the row is [H | g | s] itself: its last entry is the block's |r|^2 when the tile is the block
     static constexpr int count(int part) { return SPLIT::count(D::PL, part); }
     static __device__ __forceinline__ int entry(int part, int l) { return SPLIT::entry(D::PL, part, l); }
     static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
@@ -56,6 +57,7 @@ struct MomentForm {
     static constexpr int PI = IntrSize<MODEL>::value;
     static constexpr int NROW = MomRows<PI>::N, NPARTS = NP, NTOT = MomLayout<PI>::N;
     static constexpr int MINW = MW;
+    static constexpr bool DIRECT = false;
     static constexpr int count(int part) { return MomSplit<PI, NP>::T.count[part]; }
     static __device__ __forceinline__ int entry(int part, int l) { return MomSplit<PI, NP>::T.entry[part][l]; }
     static __device__ __forceinline__ void rows(const T* bcp, const T* ip, const T* sp, T x, T y, T u, T v, double* w) {
@@ -78,7 +80,8 @@ template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW 
 // thousands of one-group tiles the kernel is a latency chain per workgroup whose throughput is the number of workgroups in flight.
 template <class FORM, int PART, int NBUF, typename T, int ABL = 0, bool ONE = false>
 __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
-                                               const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out) {
+                                               const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out,
+                                               double huber_delta, double* w_out, double* s_out) {
     constexpr int NP = FORM::NPARTS, NROW = FORM::NROW, NR2 = ShareDims<FORM>::NR2;
     constexpr int NLOC = FORM::count(PART), NPAD = TransposeSum<16>::pad(NLOC);
     double acc[NPAD];
@@ -135,6 +138,15 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
         if (owner && l < NLOC) {
             const int e = FORM::entry(PART, l);
             if (e < FORM::NTOT) out[e] = acc[jj];
+            if constexpr (FORM::DIRECT) {
+                // one tile per block: the lane that holds the block's |r|^2 also leaves its robust weight (k_weights' work)
+                if (w_out && e == FORM::NTOT - 1) {
+                    double rho, wt;
+                    huber(acc[jj], huber_delta, &rho, &wt);
+                    *w_out = wt;
+                    *s_out = acc[jj];
+                }
+            }
         }
     }
 }
@@ -147,7 +159,8 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
                                                                   const T* __restrict__ Y, const T* __restrict__ u, const T* __restrict__ v,
-                                                                  int PI, double* __restrict__ partial) {
+                                                                  int PI, double* __restrict__ partial, double huber_delta = 0.0,
+                                                                  double* __restrict__ blk_w = nullptr, double* __restrict__ blk_s = nullptr) {
     __shared__ v2f64 sh[NBUF * FORM::NPARTS][ShareDims<FORM>::NR2][64];
     if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
     const int64_t w = blockIdx.x;
@@ -160,23 +173,29 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
     const T* ip = intr + static_cast<int64_t>(cam) * PI;
     const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double* out = partial + w * FORM::NTOT;
-    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out);
-    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
-    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out); }
+    double *wo = blk_w ? blk_w + w : nullptr, *so = blk_w ? blk_s + w : nullptr;  // (one tile per block: tile index = block index)
+    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
+    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------
 template <class FORM, int NBUF, typename T>
 static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
     static const bool one_ok = !(cba_exp_env("CBA_MODEB_ONEGROUP") && std::atoi(cba_exp_env("CBA_MODEB_ONEGROUP")) == 0);
+    // one tile per block and the caller wants the block weights (Engine::head_huber): the direct form leaves them on its way out
+    const bool wts = FORM::DIRECT && e.head_huber >= 0.0 && e.n_tilesB == e.n_blocks && rows == e.blk_acc.p;
+    double* wo = wts ? e.blk_w.p : nullptr;
+    double* so = wts ? e.blk_s.p : nullptr;
     if (NBUF == 1 && one_ok && e.max_tileB <= 64 * FORM::NPARTS)  // every tile is one group: the single-group kernel
         hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream,
-                           e.gate, e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+                           e.gate, e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows, e.head_huber, wo, so);
     else
         hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.gate, e.tilesB.p,
-                           e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows);
+                           e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows, e.head_huber, wo, so);
+    if (wts) e.head_weights = true;
 }
 
 template <class F64, class F32, int NBUF = 1>
