@@ -1021,6 +1021,35 @@ def test_mode_b_tile_boundaries(gpu_lib, oracle, chain):
     assert abs(c1 - helpers.oracle_cost(oracle, flat)) <= 1e-10 * max(1.0, c1)
 
 
+@pytest.mark.parametrize("kind,n_cams,n", [("ext", 9, 144), ("ext", 10, 160), ("bundle", 8, 134), ("ext", 8, 128)])
+def test_wide_reduced_systems_through_the_controller(gpu_lib, oracle, kind, n_cams, n, lm_mode):
+    """The controller kernel's memory forms (lm_ctl.hip): up to 128 shared columns the reduced matrix and every short per-column
+    array live in LDS (8-camera rig: 128, the LDS limit itself); 129 .. 136 the matrix moves to global memory while the short arrays
+    stay in LDS (8-camera hand-eye bundle: 6 + 8 x 16 = 134); above, everything is in global memory (9 and 10 cameras: 144, 160).
+    Each against the oracle at the 1e-9 bar and against the host-side form of the iteration (same decisions)."""
+    if lm_mode == "resident":
+        pytest.skip("wider than the resident kernel takes")
+    mk = (lambda: synth.scene_extrinsics(5, n_cams, spacing=0.08, noise_px=0.2, seed=5)) if kind == "ext" else \
+         (lambda: synth.scene_bundle(14, n_cams, spacing=0.04, noise_px=0.2, seed=5))
+    a, b, c = mk(), mk(), mk()
+    o = options(epsilon=1e-12, optimize_intrinsics=1) if kind == "bundle" else options(epsilon=1e-12)
+    sa = helpers.oracle_solve(oracle, a.flat, o)
+    with optim.ReprojHandle(b.flat) as h:
+        sb = h.solve(o)
+        xb = h.solve_stats()
+    with optim.ReprojHandle(c.flat) as h:
+        h.set_lm_mode(3)
+        sc = h.solve(o)
+        xc = h.solve_stats()
+    assert helpers.local_cols(b.flat) >= 22
+    assert sb.termination == sa.termination and abs(sb.iterations - sa.iterations) <= 1, (sa.report, sb.report)
+    assert abs(sb.final_cost - sa.final_cost) <= 1e-10 * sa.final_cost
+    assert helpers.param_diff(a.flat, b.flat) <= 1e-9
+    assert (sc.termination, sc.iterations, sc.successful_steps) == (sb.termination, sb.iterations, sb.successful_steps), (sb.report, sc.report)
+    assert {k: xc[k] for k in xc if k != "allreduce_doubles"} == {k: xb[k] for k in xb if k != "allreduce_doubles"}
+    assert helpers.param_diff(b.flat, c.flat) <= 1e-11
+
+
 from tests.test_host_logic import _sweep_cases  # noqa: E402
 
 
