@@ -1065,10 +1065,9 @@ struct HipBackend final : Backend {
         (void)rank;
         const Structure& s = st.s;
         ensure_pack(L);
-        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
+        const bool q1 = s.n_blocks != 0;
         st.pin_lmp.p[0] = radius;
         st.pin_lmp.p[1] = init_scale ? 1.0 : 0.0;
-        (void)q2;
         ctl_huber = huber;
         if (q1) enqueue_normal_eq_head(0, huber);
         enqueue_system(huber, q1, q1, constrained, 0, L, 0);
@@ -1243,8 +1242,7 @@ struct HipBackend final : Backend {
     void ctl_new(double huber, bool first, const PackLayout& L, const AllReduce& ar, int rank) override {
         (void)rank;
         const Structure& s = st.s;
-        const bool q1 = s.n_blocks != 0, q2 = s.n_views != 0;
-        (void)q2;
+        const bool q1 = s.n_blocks != 0;
         ctl_huber = huber;
         if (q1) enqueue_normal_eq_head(0, huber);
         enqueue_system(huber, q1, q1, ctl_constrained, 0, L, 0);
