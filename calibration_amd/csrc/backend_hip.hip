@@ -1,13 +1,15 @@
 // backend_hip.hip — the HIP implementation of cba::Backend (lm_core.hpp) on an Engine, plus the
 // collective glue (host callback or RCCL over xGMI).
 //
-// Kernels here are the O(#views) / O(#blocks) part of one LM step:
-//   k_weights        rho'(s_b) per residual block (ceres HuberLoss + corrector)
-//   k_cam_partial    weighted per-camera sums of the block normal equations (chunked, fixed order)
-//   k_schur_view     per private view: damped H_pp = L L^T, y = L^-1 g_p, Z_b = L^-1 E_b
-//   k_schur_syrk     S_schur = sum_v Z_v^T Z_v, 64x64 output tiles, 4x4 register micro-tiles
-//   k_schur_gvec     g_schur = sum_v Z_v^T y_v
-//   k_backsub        delta_p, trial poses, step norms and the views' share of the model-cost terms
+// Kernels here are the O(#views) / O(#blocks) part of one LM step.  The bodies:
+//   weights          rho'(s_b) per residual block (ceres HuberLoss + corrector)
+//   cam_partial      weighted per-camera sums of the block normal equations (chunked, fixed order), seg_sum their totals
+//   schur_view_wave  per private view, one wavefront: damped H_pp = L L^T, y = L^-1 g_p, Z_b = L^-1 E_b
+//   schur_syrk       S_schur = sum_v Z_v^T Z_v (+ g_schur = sum_v Z_v^T y_v), 64x64 output tiles, VALU or fp64 MFMA
+//   backsub          delta_p, trial poses, step norms and the views' share of the model-cost terms
+// In the LM loop the bodies that do not depend on each other share launches (k_step_head, k_sys_stage2, k_sys_stage3, k_sys_pack:
+// "the fused stages" below); the one-kernel-per-body launches remain for the paths off the loop.  The decision itself is the
+// controller kernel's (lm_ctl.hip), queued behind the exchange by the ctl_* functions of HipBackend.
 // All reductions are two-stage with a fixed summation order (no atomics on fp64), so runs are
 // bitwise reproducible and 1/2/4/8-rank runs differ only by the all-reduce's own rounding.
 #include <rccl/rccl.h>
