@@ -206,6 +206,19 @@ CBA_HD double ctl_shared_gmax(TM& tm, const CtlView& V) {
             if (V.eff[i]) m = fmax(m, fabs(V.gc[i]));
         return tm.max(m);
     }
+    if (V.chain == CH_INTRINSIC) {
+        // the shared blocks are intrinsics only (Euclidean, fx, fy >= 0): |Plus(x, -g) - x| entry by entry, in ctl_plus' own arithmetic,
+        // without the trip through x_tmp in global memory
+        if (V.intr_var)
+            for (int i = tm.tid(); i < V.n_cams * V.PI; i += tm.size()) {
+                const int c = i / V.PI, k = i - c * V.PI, col = ctl_intr_base(V, c) + k;
+                const double p0 = V.x_cur[i];
+                double p = p0 + (V.eff[col] ? -V.gc[col] : 0.0);
+                if (k < 2) p = fmax(p, 0.0);
+                m = fmax(m, fabs(p - p0));
+            }
+        return tm.max(m);
+    }
     for (int i = tm.tid(); i < V.n; i += tm.size()) V.xs[i] = V.eff[i] ? -V.gc[i] : 0.0;
     tm.sync();
     (void)ctl_plus(tm, ctl_plus_view(V), V.x_cur, V.xs, V.x_tmp);
