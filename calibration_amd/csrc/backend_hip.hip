@@ -1203,10 +1203,10 @@ struct HipBackend final : Backend {
     void run_ctl(int mode, int flag) {
         launch_lm_ctl(st.ctl_view, mode, flag, e.stream);
         ++ctl_invocations;
-        // what ctl_wait() sleeps on when polling the record has taken too long: an event right behind THIS launch (the stream may
-        // already hold the gated head of the next step behind it, which must not be waited for)
-        if (!st.ctl_done) CBA_HIP(hipEventCreateWithFlags(&st.ctl_done, hipEventDisableTiming));
-        CBA_HIP(hipEventRecord(st.ctl_done, e.stream));
+        if (st.ctl_event) {  // (experiment builds: ctl_wait sleeping on an event behind THIS launch; see there why not)
+            if (!st.ctl_done) CBA_HIP(hipEventCreateWithFlags(&st.ctl_done, hipEventDisableTiming));
+            CBA_HIP(hipEventRecord(st.ctl_done, e.stream));
+        }
     }
     bool ctl_begin(const CtlSetup& cs, const PackLayout& L) override {
         if (!st.lm_ctl_mode) return false;
@@ -1401,26 +1401,31 @@ struct HipBackend final : Backend {
             }
         }
         if (*seq < want) {
-            if (!e.rccl_comm) {
-                CBA_HIP(hipEventSynchronize(st.ctl_done));
-            } else {
-                // A collective is queued in front of the controller: a peer that failed (threw out of its solve and aborted its
-                // communicator, died, hung) must not leave this rank waiting for ever.  Poll the event, watch the communicator's
-                // asynchronous error state and a deadline; on either, abort the communicator (which releases the stream) and fail.
-                const auto t0 = std::chrono::steady_clock::now();
-                for (;;) {
-                    const hipError_t q = hipEventQuery(st.ctl_done);
-                    if (q == hipSuccess) break;
-                    if (q != hipErrorNotReady) CBA_HIP(q);
-                    ncclResult_t async = ncclSuccess;
-                    (void)ncclCommGetAsyncError(reinterpret_cast<ncclComm_t>(e.rccl_comm), &async);
-                    const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(st.rccl_timeout_s);
-                    if (async != ncclSuccess || late) {
-                        rccl_abort(e);
-                        throw HipError(late ? "RCCL exchange: no progress within the deadline (a peer rank failed or hung); communicator aborted"
-                                            : std::string("RCCL exchange failed on a peer: ") + ncclGetErrorString(async) + "; communicator aborted");
-                    }
-                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+            // Still not there (a Mode B pass over 1e7+ observations is in front of the controller): nap and look again.  No event is
+            // recorded behind the controller for this - an event record is a barrier packet between the controller and the head of
+            // the next step that is already queued behind it (~6 us of idle chip per step) - and the stream itself cannot be waited
+            // on: it holds that next step.  Every millisecond or so: has the stream died or drained without a record, has a peer's
+            // collective failed (a rank that threw out of its solve aborts its communicator; this rank must not wait for ever), is
+            // the deadline over?
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int naps = 0; *seq < want; ++naps) {
+                std::this_thread::sleep_for(std::chrono::microseconds(st.ctl_event ? 0 : 30));
+                if (st.ctl_event) {  // (experiment builds: the event-based wait of the first version)
+                    CBA_HIP(hipEventSynchronize(st.ctl_done));
+                    break;
+                }
+                if ((naps & 31) != 31) continue;
+                const hipError_t q = hipStreamQuery(e.stream);
+                if (q == hipSuccess) break;  // the stream is empty: the record is there, or never will be
+                if (q != hipErrorNotReady) CBA_HIP(q);
+                if (!e.rccl_comm) continue;
+                ncclResult_t async = ncclSuccess;
+                (void)ncclCommGetAsyncError(reinterpret_cast<ncclComm_t>(e.rccl_comm), &async);
+                const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(st.rccl_timeout_s);
+                if (async != ncclSuccess || late) {
+                    rccl_abort(e);
+                    throw HipError(late ? "RCCL exchange: no progress within the deadline (a peer rank failed or hung); communicator aborted"
+                                        : std::string("RCCL exchange failed on a peer: ") + ncclGetErrorString(async) + "; communicator aborted");
                 }
             }
             if (*seq < want) throw HipError("LM controller: the control record did not arrive");
@@ -1549,6 +1554,7 @@ void init_lm_state(Engine& e, const cba_reproj_problem& d, bool have_records) {
     if (const char* env = std::getenv("CBA_SYRK_MFMA")) st->syrk_mfma = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_SCHUR_WAVE")) st->schur_wave = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_LM_FUSE")) st->fuse_small = std::atoi(env);
+    if (const char* env = cba_exp_env("CBA_LM_CTL_EVENT")) st->ctl_event = std::atoi(env);
     if (const char* env = cba_exp_env("CBA_SYNC_SPIN")) st->sync_spin = std::atoi(env);
     if (const char* env = std::getenv("CBA_LM_GRAPH")) {
         const int v = std::atoi(env);

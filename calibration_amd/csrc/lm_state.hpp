@@ -30,7 +30,8 @@ struct HipLMState {
     // the ONE wait of an LM step: hipStreamSynchronize sleeps on an interrupt (20-50 us to wake up on ROCm 7.2, more than the
     // whole host side of a step); polling an event recorded behind the stage returns within a few us (CBA_SYNC_SPIN=0: sleep)
     hipEvent_t step_done = nullptr;
-    hipEvent_t ctl_done = nullptr;  // recorded behind every controller launch (ctl_wait)
+    hipEvent_t ctl_done = nullptr;  // experiment builds (CBA_LM_CTL_EVENT=1): recorded behind every controller launch for ctl_wait to sleep on
+    int ctl_event = 0;
     int sync_spin = 1;
     ~HipLMState() {
         if (step_done) (void)hipEventDestroy(step_done);
@@ -76,7 +77,7 @@ struct HipLMState {
     int ctl_n = -1;             // reduced size the buffers above were laid out for
     int rccl_timeout_s = 120;   // ctl_wait gives a step's collective this long before it aborts the communicator (CBA_RCCL_TIMEOUT_S)
     int ctl_prelaunch = 1;      // queue the head of the next step behind the controller before its decision is known (CBA_LM_PRELAUNCH)
-    int ctl_poll_us = 400;      // how long ctl_wait polls the record before it sleeps on the stream
+    int ctl_poll_us = 2000;     // how long ctl_wait spins on the record before it starts napping between looks
     int lm_ctl_mode = 1;        // 1 = the controller form of the host-driven iteration (default), 0 = the host-side form (CBA_LM_CTL)
 };
 
