@@ -300,7 +300,7 @@ class LMDriver {
             return std::chrono::duration<double, std::micro>(b - a).count();
         };
         double t_wait = 0, t_queue = 0;
-        int n_waits = 0;
+        int n_waits = 0, n_head_queued = 0;  // n_head_queued: waits that returned with the next step's head already on the stream
         double rec[CS_COUNT];
         auto wait = [&] {
             const auto a = now();
@@ -324,6 +324,7 @@ class LMDriver {
             }
             bool queued_spec = false;  // the last thing queued in this pass is a speculative step
             if (pre && rec[CS_GO] != 0.0) {  // as predicted: the step's head is already running; queue the rest
+                ++n_head_queued;
                 be_.ctl_step_tail(huber, L_, ar_, rank_);
                 queued_spec = true;
             } else {
@@ -377,8 +378,10 @@ class LMDriver {
         out->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (timing)
             std::fprintf(stderr, "[cba timing] solve %.1f us, %d iterations, %d waits: waiting %.1f us, host between a wait and the end of its "
-                         "launches %.1f us (%.1f per wait), controller invocations out of turn %d\n", out->solve_seconds * 1e6, iter, n_waits,
-                         t_wait, t_queue, t_queue / std::max(1, n_waits), static_cast<int>(rec[CS_N_WASTED]));
+                         "launches %.1f us (%.1f per wait; the host computes nothing there: it reads the record and queues launches), %d of the "
+                         "waits returned with the next step's head already queued behind the controller (chip idle for the host: 0), "
+                         "controller invocations out of turn %d\n", out->solve_seconds * 1e6, iter, n_waits, t_wait, t_queue,
+                         t_queue / std::max(1, n_waits), n_head_queued, static_cast<int>(rec[CS_N_WASTED]));
         if (timing && rec[CS_PROF + CP_PUBLISH] > 0.0) {
             static const char* const names[CTL_NPROF] = {"entry", "adopt", "gradient norm", "assemble", "factorise", "back-substitute", "plus",
                                                          "model terms", "decide", "publish", "", ""};
