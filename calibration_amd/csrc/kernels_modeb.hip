@@ -248,7 +248,7 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
             else launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>>(e, rows);
         } else {
             if ((variant & 15) == 5) launch_both<MomentForm<CAM_SCHEIMPFLUG, 5, double>, MomentForm<CAM_SCHEIMPFLUG, 5, float>>(e, rows);
-            else if ((variant & 15) == 2) launch_both<MomentForm<CAM_SCHEIMPFLUG, 3, double>, MomentForm<CAM_SCHEIMPFLUG, 3, float>>(e, rows);
+            else if ((variant & 15) == 3) launch_both<MomentForm<CAM_SCHEIMPFLUG, 3, double>, MomentForm<CAM_SCHEIMPFLUG, 3, float>>(e, rows);
             else launch_both<MomentForm<CAM_SCHEIMPFLUG, 4, double>, MomentForm<CAM_SCHEIMPFLUG, 4, float>>(e, rows);
         }
     }
