@@ -131,7 +131,7 @@ def main():
     ms_b_first = h.normal_eq_timed(2, 10)
     ms_b = h.normal_eq_timed(200, 50)
     flop_per_obs, valu_per_obs = 605, 374  # tools/isa_mix.py on the shipped kernel (profiles/r03_modeb_isa_mix.txt)
-    mode_b = {"kernel": "k_ne_shared<DirectForm<INTRINSIC,PINHOLE_BC,2 parts>> + k_tile_sum", "ms_per_pass": ms_b,
+    mode_b = {"kernel": "k_ne_shared<DirectForm<INTRINSIC,PINHOLE_BC,2 parts>> (one tile per view at this size: no k_tile_sum)", "ms_per_pass": ms_b,
               "ms_per_pass_right_after_mode_a": ms_b_first, "timing": "200 warm-up passes, 50 timed (HIP events); the other figure: 2 + 10",
               "bound": "fp64 vector issue",
               "flop_per_obs": flop_per_obs, "valu_instructions_per_obs": valu_per_obs, "achieved_TFLOPs": flop_per_obs * n_obs / (ms_b * 1e-3) / 1e12,
@@ -233,7 +233,7 @@ def main():
                                    "mode_b_ms_per_pass_this_rank": ms_b3, "obs_this_rank": int(sc3.flat.n_obs), "scene_gen_s": gen3,
                                    # k_ne_shared<MomentForm<PINHOLE_BC, 4 parts>>: 616 FLOP in 410 vector instructions per observation
                                    # (tools/isa_mix.py, profiles/r03_modeb_isa_mix.txt), against the 78.6 TFLOP/s fp64 vector peak
-                                   "mode_b": {"kernel": "k_ne_shared<MomentForm<PINHOLE_BC,4 parts>> + k_tile_sum + k_mom_expand", "flop_per_obs": 616,
+                                   "mode_b": {"kernel": "k_ne_shared<MomentForm<PINHOLE_BC,4 parts>> + k_mom_expand (one tile per block at this size)", "flop_per_obs": 616,
                                               "valu_instructions_per_obs": 410, "bound": "fp64 vector issue",
                                               "achieved_TFLOPs": 616 * int(sc3.flat.n_obs) / (ms_b3 * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
                                               "frac": 616 * int(sc3.flat.n_obs) / (ms_b3 * 1e-3) / 78.6e12}}
