@@ -553,7 +553,10 @@ def solution_gap_report(orc, hm, fa, fb, opts, k_weak=3) -> dict:
     ds = dk / D
     c2 = (V.T @ ds) ** 2
     tot = float(c2.sum())
-    return dict(kappa=float(wv[-1] / max(wv[0], 1e-300)), weak_share=float(c2[:k_weak].sum() / tot) if tot > 0 else 1.0,
+    # the weak directions: the k_weak weakest, or - a rig brings one flat valley PER CAMERA - every direction at least six orders
+    # below the strongest (the ones that make the condition number what it is), whichever set is larger
+    n_weak = max(k_weak, int(np.count_nonzero(wv <= 1e-6 * wv[-1])))
+    return dict(kappa=float(wv[-1] / max(wv[0], 1e-300)), weak_share=float(c2[:n_weak].sum() / tot) if tot > 0 else 1.0, n_weak=n_weak,
                 predicted_cost_gap=float(0.5 * dk @ Hk @ dk + abs(g[keep] @ dk)), outside=float(np.abs(d[~keep]).max()) if (~keep).any() else 0.0,
                 n_free=int(keep.sum()))
 
@@ -590,15 +593,20 @@ def planar_pose_gap_report(orc, view, K, nr, pa6, pb6, k_weak=2) -> dict:
     Nin = Ain.T @ Ain
     Din = 1.0 / np.sqrt(np.diag(Nin))
     win = np.linalg.eigvalsh(Nin * Din[:, None] * Din[None, :])
-    return dict(kappa=float(wv[-1] / max(wv[0], 1e-300)), weak_share=float(c2[:k_weak].sum() / tot) if tot > 0 else 1.0,
+    # the weak directions: the k_weak weakest, or - a rig brings one flat valley PER CAMERA - every direction at least six orders
+    # below the strongest (the ones that make the condition number what it is), whichever set is larger
+    n_weak = max(k_weak, int(np.count_nonzero(wv <= 1e-6 * wv[-1])))
+    return dict(kappa=float(wv[-1] / max(wv[0], 1e-300)), weak_share=float(c2[:n_weak].sum() / tot) if tot > 0 else 1.0, n_weak=n_weak,
                 predicted_cost_gap=float(0.5 * d @ H @ d + abs(g @ d)), outside=0.0, n_free=6,
                 inner_kappa=float(win[-1] / max(win[0], 1e-300)))
 
 
 def gap_category(rep: dict, cost_a: float, cost_b: float, iters=(0, 0), share=0.95, eps=1e-12) -> str:
     """The classification rule for a parity gap above the bar (tools/fuzz_gpu.py, tests).  Three benign categories:
-      "weak-direction"       nearly all of the scaled difference in the weakest eigen-directions of an ill-conditioned Hessian
-                             (condition number > 1e6): two correct solvers that differ by rounding end apart IN THAT VALLEY;
+      "weak-direction"       nearly all of the scaled difference in the weak eigen-directions of an ill-conditioned Hessian
+                             (condition number > 1e6; weak = the three weakest, or all that lie six orders below the strongest:
+                             a rig has one flat valley per camera): two correct solvers that differ by rounding end apart IN
+                             THAT VALLEY;
       "stopping-resolution"  the two end points are closer than the solvers' own stopping rule can tell apart: Ceres stops when
                              |dcost| <= eps cost, and the quadratic model prices the whole displacement between them at no more
                              than 4 eps cost - 10 eps cost when one solver did take a step more than the other: at a linear

@@ -208,6 +208,10 @@ PINNED_FUZZ = [  # found by tools/fuzz_gpu.py in round 2 (profiles/r02_fuzz_*.js
     # (6 unknowns, kappa 18), 18 vs 17 iterations, predicted cost gap 4.3 eps cost
     dict(kind="bundle", model=0, seed=210579, noise=0.1, okw=dict(huber_delta=0.3, optimize_skew=0, optimize_intrinsics=0, optimize_extrinsics=0,
                                                                    optimize_target_pose=1), nv=5, nc=1, grid=(9, 5)),
+    # ... and of a second pair of 3000-case sweeps (seeds 21 / 22): a three-camera Scheimpflug bundle with free skew, kappa 2.8e9 -
+    # one flat valley per camera, so 79 % of the gap sits in the three weakest directions and the rest in the next ones
+    dict(kind="bundle", model=1, seed=69134, noise=0.1, okw=dict(huber_delta=0.3, optimize_skew=1, optimize_intrinsics=1, optimize_extrinsics=1,
+                                                                  optimize_target_pose=0), nv=4, nc=3, grid=(6, 10)),
 ]
 
 
