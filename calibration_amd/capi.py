@@ -161,6 +161,7 @@ PROTOTYPES = {
     "cba_reproj_covariance": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), c_double_p]),
     "cba_reproj_covariance_shared_dim": (C.c_int64, [C.c_void_p]),
     "cba_reproj_covariance_shared": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), c_double_p]),
+    "cba_reproj_covariance_views": (C.c_int32, [C.c_void_p, C.POINTER(CbaOptions), C.c_int32, c_int32_p, c_double_p]),
     "cba_reproj_set_allreduce": (C.c_int32, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32]),
     "cba_rccl_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
     "cba_reproj_init_rccl": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),

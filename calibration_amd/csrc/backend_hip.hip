@@ -1783,5 +1783,10 @@ void compute_covariance(Engine& e, const cba_options& o, double* cov, bool share
     LMDriver drv = make_driver(e, be);
     drv.covariance(o, cov, shared_only);
 }
+void compute_covariance_views(Engine& e, const cba_options& o, const int32_t* views, int n_sel, double* view_cov) {
+    HipBackend be(e, *lm_state(e));
+    LMDriver drv = make_driver(e, be);
+    drv.covariance(o, nullptr, true, views, n_sel, view_cov);
+}
 
 }  // namespace cba

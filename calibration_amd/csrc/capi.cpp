@@ -815,6 +815,16 @@ cba_status cba_reproj_covariance_shared(cba_reproj* h, const cba_options* opts, 
     });
 }
 
+cba_status cba_reproj_covariance_views(cba_reproj* h, const cba_options* opts, int32_t n_sel, const int32_t* view_idx, double* cov7x7) {
+    return guarded([&] {
+        Engine& e = *as_engine(h);
+        if (!opts || n_sel < 0 || (n_sel > 0 && (!view_idx || !cov7x7))) throw std::invalid_argument("null argument");
+        if (e.chain == CBA_CHAIN_BUNDLE) throw std::invalid_argument("the bundle chain has no per-view poses");
+        CBA_HIP(hipSetDevice(e.device));
+        if (n_sel > 0) compute_covariance_views(e, *opts, view_idx, n_sel, cov7x7);
+    });
+}
+
 cba_status cba_reproj_set_allreduce(cba_reproj* h, cba_allreduce_fn fn, void* user, int32_t n_ranks, int32_t rank) {
     return guarded([&] {
         Engine& e = *as_engine(h);

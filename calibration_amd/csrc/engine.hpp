@@ -275,6 +275,7 @@ void solve_lm(Engine& e, const cba_options& o, cba_summary* out);
 void solve_stats(const Engine& e, int64_t stats8[8]);  // ExchangeStats of the last host-driven solve
 void set_lm_mode(Engine& e, int mode);  // 0 host-driven iteration, 1 automatic (default), 2 resident kernel whenever it can run the problem
 void compute_covariance(Engine& e, const cba_options& o, double* cov, bool shared_only = false);
+void compute_covariance_views(Engine& e, const cba_options& o, const int32_t* views, int n_sel, double* view_cov);
 int64_t covariance_dim(const Engine& e);
 int64_t shared_covariance_dim(const Engine& e);
 void engine_allreduce(Engine& e, double* host_buf, int64_t count);

@@ -664,7 +664,12 @@ class LMDriver {
         return n;
     }
 
-    void covariance(const cba_options& o, double* cov, bool shared_only = false) {
+    // sel_views / view_cov (with shared_only): the marginal covariance of the poses of the listed (local) views on demand,
+    // view_cov [n_sel][7 x 7] in ambient coordinates [quaternion (4), translation (3)] - the diagonal blocks the reference-layout
+    // matrix holds for those views, from the same Schur pieces: T_vv = H_pp^-1 + W_v S_cc W_v^T, W_v = H_pp^-1 E_v, lifted by
+    // the quaternion's PlusJacobian.  A constant view gets zeros.  cov may be nullptr then (only the view blocks are wanted).
+    void covariance(const cba_options& o, double* cov, bool shared_only = false, const int32_t* sel_views = nullptr, int n_sel = 0,
+                    double* view_cov = nullptr) {
         setup(o);
         const int n = s_.nsh, PL = s_.PL, NH = s_.NH, NACC = s_.NACC;
         if (!shared_only && covariance_dim() > 20000)
@@ -777,6 +782,44 @@ class LMDriver {
                 if (dmin <= rank_tol) throw std::runtime_error("covariance: rank deficient Jacobian (reduced system)");
             }
             chol_inverse(Lc, na, Scc);
+        }
+        if (view_cov) {
+            std::vector<int> fidx(s_.n_views, -1);
+            for (int fv = 0; fv < nv; ++fv) fidx[free_views[fv]] = fv;
+            std::vector<double> WS(static_cast<size_t>(6) * std::max(na, 1));
+            for (int k = 0; k < n_sel; ++k) {
+                const int v = sel_views[k];
+                if (v < 0 || v >= s_.n_views) throw std::invalid_argument("covariance: view index out of range");
+                double* out = view_cov + static_cast<size_t>(k) * 49;
+                for (int i = 0; i < 49; ++i) out[i] = 0.0;
+                const int fv = fidx[v];
+                if (fv < 0) continue;
+                const double* Wv = &W[static_cast<size_t>(fv) * 6 * std::max(na, 1)];
+                double T6[36];
+                for (int i = 0; i < 6; ++i)
+                    for (int b = 0; b < na; ++b) {
+                        double sum = 0;
+                        for (int a = 0; a < na; ++a) sum += Wv[static_cast<size_t>(i) * na + a] * Scc[static_cast<size_t>(a) * na + b];
+                        WS[static_cast<size_t>(i) * na + b] = sum;
+                    }
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double sum = Hinv[static_cast<size_t>(fv) * 36 + i * 6 + j];
+                        for (int a = 0; a < na; ++a) sum += WS[static_cast<size_t>(i) * na + a] * Wv[static_cast<size_t>(j) * na + a];
+                        T6[i * 6 + j] = sum;
+                    }
+                const double* q = &view_[7 * static_cast<size_t>(v)];
+                double P[7][6] = {{-q[1], -q[2], -q[3], 0, 0, 0}, {q[0], q[3], -q[2], 0, 0, 0}, {-q[3], q[0], q[1], 0, 0, 0},
+                                  {q[2], -q[1], q[0], 0, 0, 0}, {0, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 0, 1}};
+                for (int r = 0; r < 7; ++r)
+                    for (int c = 0; c < 7; ++c) {
+                        double sum = 0;
+                        for (int i = 0; i < 6; ++i)
+                            for (int j = 0; j < 6; ++j) sum += P[r][i] * T6[i * 6 + j] * P[c][j];
+                        out[r * 7 + c] = sum;
+                    }
+            }
+            if (!cov) return;
         }
         // tangent covariance: [shared active (na) | free views (6 each)]
         const int nt = shared_only ? na : na + 6 * nv;

@@ -435,6 +435,17 @@ class ReprojHandle:
         capi.check(self.lib, st)
         return cov
 
+    def covariance_views(self, opts: CbaOptions, view_idx) -> Optional[np.ndarray]:
+        """Marginal 7 x 7 covariance [quaternion, translation] of the poses of the listed views (cba_reproj_covariance_views):
+        the diagonal blocks of the reference-layout matrix without forming it.  None if rank deficient."""
+        idx = np.ascontiguousarray(view_idx, dtype=np.int32)
+        out = np.zeros((len(idx), 7, 7))
+        st = self.lib.cba_reproj_covariance_views(self.h, C.byref(opts), len(idx), i32ptr(idx), dptr(out))
+        if st == capi.CBA_ERR_RUNTIME:
+            return None
+        capi.check(self.lib, st)
+        return out
+
     def set_allreduce(self, fn, n_ranks: int, rank: int):
         """fn(np.ndarray) sums the array in place across ranks (host buffers)."""
 

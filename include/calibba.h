@@ -258,6 +258,13 @@ cba_status cba_reproj_covariance(cba_reproj* h, const cba_options* opts, double*
  * at 4000).  Equal to the corresponding rows/columns of cba_reproj_covariance. */
 int64_t cba_reproj_covariance_shared_dim(const cba_reproj* h);
 cba_status cba_reproj_covariance_shared(cba_reproj* h, const cba_options* opts, double* cov /*[dim*dim]*/);
+/* ... and the per-view blocks on demand: the marginal covariance of the poses of the listed views
+ * (indices local to this handle), cov7x7 [n_sel][7][7] in ambient coordinates [quaternion (4), translation (3)] - the diagonal
+ * blocks cba_reproj_covariance holds for those views, from the same Schur pieces, O(#views + n_sel) work instead of
+ * O(#views^2); zeros for a view the gauge holds constant.  Same rank test as cba_reproj_covariance_shared.
+ * INTRINSIC / EXTRINSIC chains (the bundle chain has no per-view poses).  ceresutils.h:69-126. */
+cba_status cba_reproj_covariance_views(cba_reproj* h, const cba_options* opts, int32_t n_sel, const int32_t* view_idx,
+                                       double* cov7x7);
 
 /* ---- multi-GPU: views sharded across ranks, one sum-all-reduce per LM linear solve ---------- */
 /* Host-buffer callback (any transport: gloo, MPI, ...): in-place sum of buf[count] over ranks. */

@@ -592,4 +592,16 @@ int hm_reproj_covariance_shared(const cba_reproj_problem* d, const cba_options* 
     });
 }
 
+
+// the marginal 7 x 7 pose covariance of the listed views (LMDriver::covariance, the path of cba_reproj_covariance_views)
+int hm_reproj_covariance_views(const cba_reproj_problem* d, const cba_options* o, int n_sel, const int32_t* views, double* cov7x7) {
+    return guarded([&] {
+        Session ss;
+        load(*d, ss);
+        CpuBackend be(ss.s, *d, ss.view);
+        LMDriver drv(ss.s, be, ss.intr, ss.cam, ss.view, ss.target, [](double*, int64_t) {}, 1, 0);
+        drv.covariance(*o, nullptr, true, views, n_sel, cov7x7);
+    });
+}
+
 }  // extern "C"

@@ -86,6 +86,7 @@ def load_hostmath():
     h.hm_semidlt_step.argtypes = [C.c_int, c_int64_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, PO,
                                   c_double_p, c_double_p]
     h.hm_semidlt_solve.argtypes = SEMIDLT_SOLVE_ARGS
+    h.hm_reproj_covariance_views.argtypes = [PP, PO, C.c_int, c_int32_p, c_double_p]
     # (n_local, off, X, Y, u, v, n_total, first_view, kappa5, poses7 [all], nr, lo, hi, fixed_idx, fixed_val, n_fixed, opts, summary, ...)
     h.hm_semidlt_solve_sharded.argtypes = SEMIDLT_SOLVE_ARGS[:6] + [C.c_int, C.c_int] + SEMIDLT_SOLVE_ARGS[6:] + [capi.ALLREDUCE_FN, C.c_void_p]
     h.hm_planar_seed.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]

@@ -281,6 +281,15 @@ def test_covariance_matches_oracle(gpu_lib, oracle):
         with optim.ReprojHandle(b.flat) as h:  # shared-block marginal = leading block of the full matrix, O(#views) work
             cs = h.covariance_shared(o)
         assert cs is not None and np.array_equal(cs, cov1[:cs.shape[0], :cs.shape[0]])
+        if b.flat.n_views:  # per-view blocks on demand (cba_reproj_covariance_views) = the full matrix's diagonal blocks for those views
+            V, ns = b.flat.n_views, cs.shape[0]
+            sel = [V - 1, 0, V // 2]
+            with optim.ReprojHandle(b.flat) as h:
+                cv = h.covariance_views(o, sel)
+            for k, v in enumerate(sel):
+                rows = list(range(ns + 4 * v, ns + 4 * v + 4)) + list(range(ns + 4 * V + 3 * v, ns + 4 * V + 3 * v + 3))
+                ref = cov1[np.ix_(rows, rows)]
+                assert np.abs(cv[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
 
 
 def test_large_random_scene_properties(gpu_lib):
@@ -896,6 +905,13 @@ def test_full_size_c3_properties(gpu_lib, lm_mode):
                 "line_search_evaluations"] + (s.successful_steps - xs["speculation_hits"] - xs["speculation_misses"])
         cs = h.covariance_shared(o)
         assert cs is not None, gpu_lib.cba_last_error().decode()
+        # per-view pose covariance on demand at this size (the reference-layout matrix would be 28 000^2): view 0 is the gauge
+        # (constant: zeros), the others symmetric positive semi-definite with a millimetre-scale translation sigma or better
+        cv = h.covariance_views(o, [0, 1999, 3999])
+        assert cv is not None and not cv[0].any()
+        for blk in cv[1:]:
+            assert np.abs(blk - blk.T).max() <= 1e-12 * np.abs(blk).max() and np.linalg.eigvalsh(blk).min() >= -1e-12 * np.abs(blk).max()
+            assert 0.0 < np.sqrt(np.diag(blk)[4:]).max() < 1e-3
         # the same solve again from the same start on the same handle: bitwise identical end state
         h.set_params(intr=start[0], cam_pose=start[1], view_pose=start[2])
         s2 = h.solve(o)

@@ -489,6 +489,17 @@ def test_covariance_assembly_matches_oracle(oracle, hostmath, kind):
     cov2 = np.zeros((ns, ns))
     assert hostmath.hm_reproj_covariance_shared(C.byref(d), C.byref(o), dptr(cov2)) == 0, hostmath.hm_last_error()
     assert np.array_equal(cov2, cov1[:ns, :ns])
+    # ... and the per-view blocks on demand are the diagonal blocks the full matrix holds for those views ([quats | translations]
+    # after the shared blocks), constant views included (zeros)
+    if not kind.startswith("bundle"):
+        V = b.flat.n_views
+        sel = np.array([V - 1, 0, V // 2], dtype=np.int32)
+        cv = np.zeros((len(sel), 7, 7))
+        assert hostmath.hm_reproj_covariance_views(C.byref(d), C.byref(o), len(sel), sel.ctypes.data_as(C.POINTER(C.c_int32)), dptr(cv)) == 0, hostmath.hm_last_error()
+        for k, v in enumerate(sel):
+            rows = list(range(ns + 4 * v, ns + 4 * v + 4)) + list(range(ns + 4 * V + 3 * v, ns + 4 * V + 3 * v + 3))
+            ref = cov1[np.ix_(rows, rows)]
+            assert np.abs(cv[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), (kind, v)
 
 
 def test_shard_views_partitions_the_problem():
