@@ -221,6 +221,9 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
         if (e.model == CAM_PINHOLE_BC) {
             if (dparts == 4) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, float>>(e, rows);
             else if (dparts == 3) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, float>>(e, rows);
+#ifdef CBA_EXPERIMENTS
+            else if (variant & 16) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>, 2>(e, rows);  // double-buffered rows: one barrier per group
+#endif
             else launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>>(e, rows);
         } else {
             if (dparts == 4) launch_both<DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<4>, double>, DirectForm<CH_INTRINSIC, CAM_SCHEIMPFLUG, SplitRoundRobin<4>, float>>(e, rows);
