@@ -81,8 +81,15 @@ template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW 
 template <class FORM, int PART, int NBUF, typename T, int ABL = 0, bool ONE = false>
 __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
                                                const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out,
-                                               double huber_delta, double* w_out, double* s_out) {
+                                               double huber_delta, double* w_out, double* s_out, volatile int* flags = nullptr) {
     constexpr int NP = FORM::NPARTS, NROW = FORM::NROW, NR2 = ShareDims<FORM>::NR2;
+    // ABL == 4 (experiment builds; results are RIGHT): per-chunk flags in LDS instead of the two workgroup barriers per group.
+    // flags[p] = groups whose rows wavefront p has published, flags[NP + p] = reads of chunk p's rows completed so far (all groups).
+    // A wavefront waits only for the chunk it is about to read, and before rewriting its own rows for the reads of the last group.
+    constexpr bool FLAGS = ABL == 4;
+    auto spin_until = [&](int idx, int want) {
+        for (int it = 0; it < (1 << 22) && flags[idx] < want; ++it) __builtin_amdgcn_s_sleep(1);  // (bounded: a bug must not hang the chip)
+    };
     constexpr int NLOC = FORM::count(PART), NPAD = TransposeSum<16>::pad(NLOC);
     double acc[NPAD];
 #pragma unroll
@@ -104,6 +111,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
         // still have the barrier and the other chunks' accumulation to arrive.
         const bool more = !ONE && j + 64 * NP < t.count;
         const int64_t in = t.start + j + 64 * NP, k2n = t.xy_start + j + 64 * NP;
+        if (FLAGS && g > 0) spin_until(NP + PART, (NP - 1) * g);  // every reader is done with this wavefront's rows of the last group
         if (j < t.count) {
             double w[2 * NR2];
             FORM::rows(bcp, ip, sp, xc, yc, uc, vc, w);
@@ -114,21 +122,33 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
             FORM::template accumulate<PART>(w, static_cast<double>(xc), static_cast<double>(yc), acc);
             if (more) { xc = X[k2n]; yc = Y[k2n]; }
         }
-        if (!(ABL & 1)) __syncthreads();  // every wavefront's rows of this group are in LDS
+        if (FLAGS) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the rows are in LDS
+            if (lane == 0) flags[PART] = g + 1;
+        } else if (!(ABL & 1)) {
+            __syncthreads();  // every wavefront's rows of this group are in LDS
+        }
 #pragma unroll
         for (int q = 1; q < NP; ++q) {
             constexpr int dummy = 0; (void)dummy;
             const int p = (PART + q) % NP;  // start with the neighbour: the NP wavefronts read NP different LDS regions at a time
             const int jo = (g * NP + p) * 64 + lane;
+            if (FLAGS) spin_until(p, g + 1);
+            double w[2 * NR2];
             if (jo < t.count) {
-                double w[2 * NR2];
 #pragma unroll
                 for (int k = 0; k < NR2; ++k) { const v2f64 d = sh[(ABL & 2) ? PART : p][k][(ABL & 2) ? 0 : lane]; w[2 * k] = d.x; w[2 * k + 1] = d.y; }
+            }
+            if (FLAGS) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // the rows are in registers: the chunk's owner may rewrite them
+                if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(flags) + NP + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (jo < t.count) {
                 const double xo = static_cast<double>(X[t.xy_start + jo]), yo = static_cast<double>(Y[t.xy_start + jo]);
                 FORM::template accumulate<PART>(w, xo, yo, acc);
             }
         }
-        if (NBUF == 1 && !(ABL & 1) && !ONE) __syncthreads();  // before the next group overwrites the rows
+        if (NBUF == 1 && !(ABL & 1) && !ONE && !FLAGS) __syncthreads();  // before the next group overwrites the rows
     }
     bool owner;
     const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
@@ -162,6 +182,11 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
                                                                   int PI, double* __restrict__ partial, double huber_delta = 0.0,
                                                                   double* __restrict__ blk_w = nullptr, double* __restrict__ blk_s = nullptr) {
     __shared__ v2f64 sh[NBUF * FORM::NPARTS][ShareDims<FORM>::NR2][64];
+    __shared__ int sync_flags[ABL == 4 ? 2 * FORM::NPARTS : 1];
+    if (ABL == 4) {
+        if (threadIdx.x < 2 * FORM::NPARTS) sync_flags[threadIdx.x] = 0;
+        __syncthreads();
+    }
     if (gate && *gate == 0.0) return;  // (kernels_reproj.hip k_block_consts: a launch queued ahead of the decision it depends on)
     const int64_t w = blockIdx.x;
     if (w >= n_tiles) return;
@@ -174,11 +199,11 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
     const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double* out = partial + w * FORM::NTOT;
     double *wo = blk_w ? blk_w + w : nullptr, *so = blk_w ? blk_s + w : nullptr;  // (one tile per block: tile index = block index)
-    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so);
-    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
-    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
-    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
-    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so); }
+    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------
@@ -222,6 +247,11 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
             if (dparts == 4) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<4>, float>>(e, rows);
             else if (dparts == 3) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<3>, float>>(e, rows);
 #ifdef CBA_EXPERIMENTS
+            else if (variant == 64) {  // per-chunk flags instead of the two barriers per group
+                using F = DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>;
+                hipLaunchKernelGGL((k_ne_shared<F, 1, double, 4>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * 2), 0, e.stream, e.gate, e.tilesB.p, e.n_tilesB,
+                                   e.bc.p, e.intr[e.active].p, e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.PI, rows);
+            }
             else if (variant & 16) launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>, 2>(e, rows);  // double-buffered rows: one barrier per group
 #endif
             else launch_both<DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, double>, DirectForm<CH_INTRINSIC, CAM_PINHOLE_BC, SplitRoundRobin<2>, float>>(e, rows);
@@ -239,6 +269,11 @@ bool launch_normal_eq_shared_rows(Engine& e, double* rows) {
             else if ((variant & 15) == 5) launch_both<MomentForm<CAM_PINHOLE_BC, 5, double>, MomentForm<CAM_PINHOLE_BC, 5, float>>(e, rows);
             else if (variant & 16) launch_both<MomentForm<CAM_PINHOLE_BC, 3, double>, MomentForm<CAM_PINHOLE_BC, 3, float>, 2>(e, rows);
 #ifdef CBA_EXPERIMENTS
+            else if (variant == 64 && !e.scalar) {  // per-chunk flags instead of the two barriers per group (results are right)
+                using F = MomentForm<CAM_PINHOLE_BC, 4, double>;
+                hipLaunchKernelGGL((k_ne_shared<F, 1, double, 4>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * 4), 0, e.stream, e.gate, e.tilesB.p, e.n_tilesB,
+                                   e.bc.p, e.intr[e.active].p, e.sd.p, e.d_blk_cam.p, e.X.p, e.Y.p, e.u.p, e.v.p, e.PI, rows);
+            }
             else if (variant >= 32 && variant != 36 && !e.scalar) {  // timing-only ablations (32 + ABL): results are wrong
                 using F = MomentForm<CAM_PINHOLE_BC, 3, double>;
                 const dim3 g(static_cast<unsigned>(e.n_tilesB)), b(64 * 3);
