@@ -314,6 +314,10 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
                 const int64_t cost = ((tiles + slots - 1) / slots) * (len / np_obs * loop + epi);
                 if (best < 0 || cost < best) { best = cost; tile_b = std::max<int64_t>(len, TILE_B); }
             }
+            if (const char* env = cba_exp_env("CBA_MODEB_TILES_PER_BLOCK")) {  // experiment builds: force k tiles per average block
+                const int64_t k = std::max(1, std::atoi(env));
+                tile_b = std::max<int64_t>(64, ((n_avg + k - 1) / k + np_obs - 1) / np_obs * np_obs);
+            }
         }
         for (int b = 0; b < d.n_blocks; ++b) {
             const int64_t n = e.blk_offset[b + 1] - e.blk_offset[b];
