@@ -78,7 +78,7 @@ template <class FORM> struct ShareDims { static constexpr int NR2 = (FORM::NROW 
 // ONE: every tile of the problem fits ONE group (<= 64 NP observations: the 88-point views of a hand-eye bundle) - no group loop,
 // no prefetch of a next group, no second barrier; the registers that frees let a third workgroup live on the CU, and with
 // thousands of one-group tiles the kernel is a latency chain per workgroup whose throughput is the number of workgroups in flight.
-template <class FORM, int PART, int NBUF, typename T, int ABL = 0, bool ONE = false>
+template <class FORM, int PART, int NBUF, typename T, int ABL = 0, bool ONE = false, bool PF2 = false>
 __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* bcp, const T* ip, const T* sp, const T* X, const T* Y,
                                                const T* u, const T* v, v2f64 (*shb)[ShareDims<FORM>::NR2][64], double* out,
                                                double huber_delta, double* w_out, double* s_out, volatile int* flags = nullptr) {
@@ -95,22 +95,27 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 #pragma unroll
     for (int e = 0; e < NPAD; ++e) acc[e] = 0.0;
     const int n_groups = ONE ? 1 : (t.count + 64 * NP - 1) / (64 * NP);  // the same for every wavefront of the workgroup
-    T xc = T(0), yc = T(0), uc = T(0), vc = T(0);
+    // PF: how many groups ahead the own chunk's x, y, u, v are loaded.  1: into the registers of the current group as soon as those
+    // are dead (~0.6 of a pass ahead).  2 (PF2): two register sets used by even / odd groups, each reloaded for the group after
+    // next right after its use (~1.6 passes ahead: a pass is ~0.7 us of issue, an HBM round trip under load longer).
+    constexpr int PF = PF2 ? 2 : 1;
+    T xa = T(0), ya = T(0), ua = T(0), va = T(0), xb = T(0), yb = T(0), ub = T(0), vb = T(0);
     {
         const int j = PART * 64 + lane;
-        if (j < t.count) { xc = X[t.xy_start + j]; yc = Y[t.xy_start + j]; uc = u[t.start + j]; vc = v[t.start + j]; }
+        if (j < t.count) { xa = X[t.xy_start + j]; ya = Y[t.xy_start + j]; ua = u[t.start + j]; va = v[t.start + j]; }
+        const int j1 = j + 64 * NP;
+        if (PF2 && j1 < t.count) { xb = X[t.xy_start + j1]; yb = Y[t.xy_start + j1]; ub = u[t.start + j1]; vb = v[t.start + j1]; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see k_normal_eq
-#pragma unroll 1
-    for (int g = 0; g < n_groups; ++g) {
+    auto step = [&](int g, T& xc, T& yc, T& uc, T& vc) __attribute__((always_inline)) {
         const int j = (g * NP + PART) * 64 + lane;
         v2f64 (*sh)[NR2][64] = shb + (NBUF == 2 ? (g & 1) * NP : 0);
         // The loads of the next group's own chunk are issued INTO the registers of the current one as soon as those are dead
         // (u, v after the rows, x, y after the own chunk's accumulation): the prefetch costs no registers of its own (8 fewer
         // than holding both sets: the general moment-form kernel fits 168 and a third workgroup lives on the CU), and the loads
         // still have the barrier and the other chunks' accumulation to arrive.
-        const bool more = !ONE && j + 64 * NP < t.count;
-        const int64_t in = t.start + j + 64 * NP, k2n = t.xy_start + j + 64 * NP;
+        const bool more = !ONE && j + PF * 64 * NP < t.count;
+        const int64_t in = t.start + j + PF * 64 * NP, k2n = t.xy_start + j + PF * 64 * NP;
         if (FLAGS && g > 0) spin_until(NP + PART, (NP - 1) * g);  // every reader is done with this wavefront's rows of the last group
         if (j < t.count) {
             double w[2 * NR2];
@@ -149,6 +154,16 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
             }
         }
         if (NBUF == 1 && !(ABL & 1) && !ONE && !FLAGS) __syncthreads();  // before the next group overwrites the rows
+    };
+    if (PF2) {
+#pragma unroll 1
+        for (int g = 0; g < n_groups; g += 2) {
+            step(g, xa, ya, ua, va);
+            if (g + 1 < n_groups) step(g + 1, xb, yb, ub, vb);  // (uniform over the workgroup: the barriers inside stay matched)
+        }
+    } else {
+#pragma unroll 1
+        for (int g = 0; g < n_groups; ++g) step(g, xa, ya, ua, va);
     }
     bool owner;
     const int base = wave_transpose_sum<NPAD>(acc, lane, &owner);
@@ -174,7 +189,7 @@ __device__ __forceinline__ void ne_shared_body(const Tile t, int lane, const T* 
 // one workgroup of FORM::NPARTS wavefronts per tile
 // MINW: wavefronts per SIMD the kernel is compiled for (0: whatever its registers allow).  A form within a few registers of the
 // next occupancy step is compiled for that step (FORM::MINW): its row buffers allow the extra workgroup on the CU.
-template <class FORM, int NBUF, typename T, int ABL = 0, bool ONE = false>
+template <class FORM, int NBUF, typename T, int ABL = 0, bool ONE = false, bool PF2 = false>
 __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(const double* __restrict__ gate, const Tile* __restrict__ tiles, int64_t n_tiles, const T* __restrict__ bc,
                                                                   const T* __restrict__ intr, const T* __restrict__ sd,
                                                                   const int32_t* __restrict__ blk_cam, const T* __restrict__ X,
@@ -199,17 +214,18 @@ __global__ __launch_bounds__(64 * FORM::NPARTS, FORM::MINW) void k_ne_shared(con
     const T* sp = sd + static_cast<int64_t>(cam) * SD_SIZE;
     double* out = partial + w * FORM::NTOT;
     double *wo = blk_w ? blk_w + w : nullptr, *so = blk_w ? blk_s + w : nullptr;  // (one tile per block: tile index = block index)
-    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags);
-    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
-    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
-    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
-    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if (wave == 0) ne_shared_body<FORM, 0, NBUF, T, ABL, ONE, PF2>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags);
+    if constexpr (FORM::NPARTS > 1) { if (wave == 1) ne_shared_body<FORM, 1, NBUF, T, ABL, ONE, PF2>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 2) { if (wave == 2) ne_shared_body<FORM, 2, NBUF, T, ABL, ONE, PF2>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 3) { if (wave == 3) ne_shared_body<FORM, 3, NBUF, T, ABL, ONE, PF2>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
+    if constexpr (FORM::NPARTS > 4) { if (wave == 4) ne_shared_body<FORM, 4, NBUF, T, ABL, ONE, PF2>(t, lane, bcp, ip, sp, X, Y, u, v, sh, out, huber_delta, wo, so, sync_flags); }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------
 template <class FORM, int NBUF, typename T>
 static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, const T* X, const T* Y, const T* u, const T* v, double* rows) {
     static const bool one_ok = !(cba_exp_env("CBA_MODEB_ONEGROUP") && std::atoi(cba_exp_env("CBA_MODEB_ONEGROUP")) == 0);
+    static const bool pf2 = cba_exp_env("CBA_MODEB_PF2") && std::atoi(cba_exp_env("CBA_MODEB_PF2")) != 0;  // prefetch two groups ahead
     // one tile per block and the caller wants the block weights (Engine::head_huber): the direct form leaves them on its way out
     const bool wts = FORM::DIRECT && e.head_huber >= 0.0 && e.n_tilesB == e.n_blocks && rows == e.blk_acc.p;
     double* wo = wts ? e.blk_w.p : nullptr;
@@ -217,6 +233,9 @@ static void launch_form(Engine& e, const T* bc, const T* intr, const T* sd, cons
     if (NBUF == 1 && one_ok && e.max_tileB <= 64 * FORM::NPARTS)  // every tile is one group: the single-group kernel
         hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream,
                            e.gate, e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows, e.head_huber, wo, so);
+    else if (NBUF == 1 && pf2)
+        hipLaunchKernelGGL((k_ne_shared<FORM, 1, T, 0, false, true>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.gate,
+                           e.tilesB.p, e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows, e.head_huber, wo, so);
     else
         hipLaunchKernelGGL((k_ne_shared<FORM, NBUF, T>), dim3(static_cast<unsigned>(e.n_tilesB)), dim3(64 * FORM::NPARTS), 0, e.stream, e.gate, e.tilesB.p,
                            e.n_tilesB, bc, intr, sd, e.d_blk_cam.p, X, Y, u, v, e.PI, rows, e.head_huber, wo, so);
