@@ -294,26 +294,13 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
     {
         std::vector<Tile> ta, tb;
         e.blk_tile_off.assign(d.n_blocks + 1, 0);
-        // Mode B / R tile length.  A tile pays one wave reduction and one partial row whatever its length (~880 instructions per
-        // wavefront against 440 per 128 observations in the direct form, ~370 against 510 per 256 in the moment form: 8 - 11 % of a
-        // 2048-observation tile, and one more row per tile for the block sum), so longer tiles are cheaper - as long as the launch
-        // still fills the chip's workgroup slots (256 CUs x 8 wavefronts / the wavefronts of a workgroup) in whole rounds.  Choose
-        // the number of tiles per average block that minimises  rounds x (passes per tile x loop + epilogue):  C2 (1000 blocks of
-        // 10 000) and C3 (32 000 blocks of 5000; also its 8-GPU share) get one tile per block, 600 blocks of 10 000 get five.
-        int64_t tile_b = TILE_B;
+        // Mode B / R tile length (structure.hpp choose_mode_b_tile): one tile per block at C2 (1000 blocks of 10 000) and C3 (32 000
+        // blocks of 5000; also its 8-GPU share), five per block for 600 blocks of 10 000, 2048 observations for small problems
+        const bool two_parts = d.chain == CBA_CHAIN_INTRINSIC && d.camera_model == CBA_CAMERA_PINHOLE_BC;
+        int64_t tile_b = choose_mode_b_tile(d.n_blocks, d.n_blocks > 0 ? e.blk_offset[d.n_blocks] : 0, two_parts, TILE_B);
         if (d.n_blocks > 0) {
-            const bool two_parts = d.chain == CBA_CHAIN_INTRINSIC && d.camera_model == CBA_CAMERA_PINHOLE_BC;
-            const int64_t np_obs = two_parts ? 128 : 256, loop = two_parts ? 440 : 510, epi = two_parts ? 880 : 370;
-            const int64_t slots = 256 * (two_parts ? 4 : 2);
+            const int64_t np_obs = two_parts ? 128 : 256;
             const int64_t n_avg = std::max<int64_t>(1, e.blk_offset[d.n_blocks] / d.n_blocks);
-            const int64_t kmax = std::max<int64_t>(1, (n_avg + TILE_B - 1) / TILE_B);
-            int64_t best = -1;
-            for (int64_t k = kmax; k >= 1; --k) {  // (ties go to the shorter tile)
-                const int64_t len = ((n_avg + k - 1) / k + np_obs - 1) / np_obs * np_obs;
-                const int64_t tiles = static_cast<int64_t>(d.n_blocks) * ((n_avg + len - 1) / len);
-                const int64_t cost = ((tiles + slots - 1) / slots) * (len / np_obs * loop + epi);
-                if (best < 0 || cost < best) { best = cost; tile_b = std::max<int64_t>(len, TILE_B); }
-            }
             if (const char* env = cba_exp_env("CBA_MODEB_TILES_PER_BLOCK")) {  // experiment builds: force k tiles per average block
                 const int64_t k = std::max(1, std::atoi(env));
                 tile_b = std::max<int64_t>(64, ((n_avg + k - 1) / k + np_obs - 1) / np_obs * np_obs);

@@ -15,6 +15,7 @@
 //   EXTRINSIC  shared = per camera [c_T_r d(3) t(3) | intr(PI)]
 //   BUNDLE     shared = [b_T_t d(3) t(3)] + per camera [g_T_c d(3) t(3) | intr(PI)]   (no private blocks)
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <vector>
@@ -124,6 +125,28 @@ inline void build_structure(const cba_reproj_problem& d, Structure& s, bool have
         std::vector<int64_t> cur(s.cam_off.begin(), s.cam_off.end() - 1);
         for (int b = 0; b < s.n_blocks; ++b) s.cam_blk[cur[s.blk_cam[b]]++] = b;
     }
+}
+
+// Mode B / R tile length for a problem of n_blocks residual blocks and n_obs observations (capi.cpp builds the tile tables with it).
+// A tile pays one wave reduction and one partial row whatever its length (~880 instructions per wavefront against 440 per 128
+// observations in the direct form of the one-camera pinhole chain, ~370 against 510 per 256 in the 4-wavefront forms: 8 - 11 % of a
+// 2048-observation tile, and one more row per tile for the block sum), so longer tiles are cheaper - as long as the launch still fills
+// the chip's workgroup slots (256 CUs x 8 wavefronts / the wavefronts of a workgroup) in whole rounds.  Picks the number of tiles per
+// AVERAGE block that minimises  rounds x (passes per tile x loop + epilogue); never shorter than min_tile (2048).
+inline int64_t choose_mode_b_tile(int64_t n_blocks, int64_t n_obs, bool two_wavefront_form, int64_t min_tile) {
+    if (n_blocks <= 0) return min_tile;
+    const int64_t np_obs = two_wavefront_form ? 128 : 256, loop = two_wavefront_form ? 440 : 510, epi = two_wavefront_form ? 880 : 370;
+    const int64_t slots = 256 * (two_wavefront_form ? 4 : 2);
+    const int64_t n_avg = std::max<int64_t>(1, n_obs / n_blocks);
+    const int64_t kmax = std::max<int64_t>(1, (n_avg + min_tile - 1) / min_tile);
+    int64_t best = -1, tile = min_tile;
+    for (int64_t k = kmax; k >= 1; --k) {  // (ties go to the shorter tile)
+        const int64_t len = ((n_avg + k - 1) / k + np_obs - 1) / np_obs * np_obs;
+        const int64_t tiles = n_blocks * ((n_avg + len - 1) / len);
+        const int64_t cost = ((tiles + slots - 1) / slots) * (len / np_obs * loop + epi);
+        if (best < 0 || cost < best) { best = cost; tile = std::max<int64_t>(len, min_tile); }
+    }
+    return tile;
 }
 
 }  // namespace cba

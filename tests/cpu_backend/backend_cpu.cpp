@@ -534,6 +534,10 @@ int hm_reproj_block_normal_eq(const cba_reproj_problem* d, int moments, double* 
 }
 
 // build_structure's validation alone (have_records: the observations arrive as per-block records, cba_reproj_create_aos)
+long long hm_choose_mode_b_tile(long long n_blocks, long long n_obs, int two_wavefront_form) {
+    return choose_mode_b_tile(n_blocks, n_obs, two_wavefront_form != 0, 2048);
+}
+
 int hm_structure_check(const cba_reproj_problem* d, int have_records) {
     return guarded([&] {
         Structure s;

@@ -502,6 +502,23 @@ def test_covariance_assembly_matches_oracle(oracle, hostmath, kind):
             assert np.abs(cv[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), (kind, v)
 
 
+def test_mode_b_tile_length_follows_the_launch_model(hostmath):
+    """structure.hpp choose_mode_b_tile (capi.cpp builds the Mode B / R tile tables with it): tiles per average block that minimise
+    rounds x (passes x loop + epilogue) over the chip's workgroup slots.  The BASELINE shapes and the traps on either side."""
+    hostmath.hm_choose_mode_b_tile.restype = C.c_longlong
+    hostmath.hm_choose_mode_b_tile.argtypes = [C.c_longlong, C.c_longlong, C.c_int]
+    pick = lambda nb, per_block, two: int(hostmath.hm_choose_mode_b_tile(nb, nb * per_block, two))
+    assert pick(20, 88, 1) == 2048 and pick(0, 0, 1) == 2048          # small problems: the shortest tile, one per block
+    assert pick(1000, 10_000, 1) >= 10_000                             # C2: 1000 workgroups fit the 1024 slots in one round
+    assert pick(32_000, 5000, 0) >= 5000 and pick(4000, 5000, 0) >= 5000  # C3 and its 8-GPU share: one tile per block
+    assert pick(600, 10_000, 1) == 2048                                # 600 long blocks: one tile each would leave 40 % of the slots idle
+    assert pick(1100, 10_000, 1) < 10_000                              # just past one round: split rather than run a near-empty second round
+    for nb, per in [(7, 3000), (513, 4097), (4000, 2049), (1, 10_000_000)]:
+        for two in (0, 1):
+            t = pick(nb, per, two)
+            assert t >= 2048 and t % (128 if two else 256) == 0
+
+
 def test_shard_views_partitions_the_problem():
     sc = synth.scene_extrinsics(9, 3, noise_px=0.1)
     parts = [synth.shard_views(sc.flat, r, 4) for r in range(4)]
