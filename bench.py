@@ -127,7 +127,7 @@ def main():
     # chunk's rows arrive through LDS): 257 FMA + 94 mul/add per wavefront and pair of chunks = 608 FLOP per observation, all of
     # it useful work (round 1 evaluated the rows once per launch: 786 FLOP issued for the same 608).
     # The chip's clock follows the load: right after the memory-bound Mode A section a pass takes ~0.18 ms, after ~35 ms of
-    # sustained fp64 work it settles at ~0.16 ms (tools/exp_modeb_warm.py).  Both are reported; `ms_per_pass` is the settled one.
+    # sustained fp64 work it settles at ~0.16 ms (tools/exp.py modeb_warm).  Both are reported; `ms_per_pass` is the settled one.
     ms_b_first = h.normal_eq_timed(2, 10)
     ms_b = h.normal_eq_timed(200, 50)
     flop_per_obs, valu_per_obs = 605, 374  # tools/isa_mix.py on the shipped kernel (profiles/r03_modeb_isa_mix.txt)

@@ -376,12 +376,12 @@ static void build_engine(const cba_reproj_problem& d, int device, Engine& e, con
 }
 
 // The Mode A output block.  Where the driver puts a multi-GB buffer decides whether k_eval streams into it at 6.2 or at 6.5 TB/s:
-// a property of the allocation, stable over its lifetime (tools/exp_placement2.py: six handles of the same problem in one process
+// a property of the allocation, stable over its lifetime (tools/exp.py placement2: six handles of the same problem in one process
 // 6.2 6.2 6.5 6.2 6.5 6.5 TB/s, the same again on re-measurement; shifting the output window inside a block by 256 B ... 64 MiB
 // changes nothing) - the pages of a plain hipMalloc are scattered over the stacks differently every time.  A physically
 // CONTIGUOUS block (hipExtMallocWithFlags, hipDeviceMallocContiguous) gets the interleaving the memory system was laid out for:
 // 6.4 - 6.5 TB/s on every handle (18 of 18; plain: 4 of 18).  Up to 4 GiB only: such a block comes back in a millisecond, a larger
-// one costs ~31 ms per GiB (tools/exp_first_eval_c3.py: 6.9 GiB 0.21 s, 59 GB 1.7 s on the first evaluation) for the +0.4 ... 2 %
+// one costs ~31 ms per GiB (tools/exp.py first_eval_c3: 6.9 GiB 0.21 s, 59 GB 1.7 s on the first evaluation) for the +0.4 ... 2 %
 // it gains at those sizes.  Falls back to the plain allocation when the runtime cannot find a contiguous range
 // (CBA_EVAL_CONTIGUOUS=0: always plain).
 template <typename T>

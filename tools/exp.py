@@ -41,7 +41,7 @@ def abl(argv):
 
 @experiment
 def abl22(argv):
-    """Timing ablation of Mode A for the two-pose chain (P = 22): full kernel / no arithmetic / no loads (see exp_abl.py for P = 16)."""
+    """Timing ablation of Mode A for the two-pose chain (P = 22): full kernel / no arithmetic / no loads (see the `abl` experiment for P = 16)."""
     from calibration_amd import optim
     from tests import synth
     sc = synth.scene_extrinsics(200, 8, rows=50, cols=100, spacing=0.008, noise_px=0.2, seed=137)
